@@ -1,0 +1,126 @@
+/*
+ * oracle.h -- CPU restatement of the Lowcash/SfM per-frame hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED.  The arithmetic of this path lives in OpenCV (knnMatch,
+ * SparsePyrLKOpticalFlow::calc, triangulatePoints, projectPoints), which is
+ * neither vendored in the reference nor installed here, and the reference
+ * ships no tests or golden vectors.  These functions restate the published
+ * OpenCV 4.x algorithms (modules/core/src/batch_distance.cpp,
+ * modules/features2d/src/matchers.cpp, modules/video/src/lkpyramid.cpp,
+ * modules/imgproc/src/pyramids.cpp, modules/calib3d/src/triangulate.cpp,
+ * modules/calib3d/src/calibration.cpp) and are anchored on the reference's
+ * own call sites, cited per function as "Source Files/<file>:<line>".
+ * They are checked against independently written NumPy vectors under
+ * tests/golden/, not against OpenCV itself.
+ */
+#ifndef SFM_ORACLE_H
+#define SFM_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same layout as cv::DMatch {queryIdx, trainIdx, imgIdx, distance}. */
+typedef struct {
+    int32_t queryIdx;
+    int32_t trainIdx;
+    int32_t imgIdx;
+    float distance;
+} orc_dmatch;
+
+enum { ORC_NORM_HAMMING = 0, ORC_NORM_L2 = 1, ORC_NORM_L2SQR = 2 };
+
+/* ---- descriptor matching ------------------------------------------------ */
+
+/* cv::BFMatcher::knnMatch(q, t, out, 2) with NORM_HAMMING, called at
+ * Source Files/feature_processing.cpp:121.  idx/dist are [nq][2]; a slot that
+ * has no neighbour (nt < 2) holds idx -1 and dist FLT_MAX.  threads<=0 means
+ * all cores (OpenMP), 1 means the scalar single-thread path. */
+void orc_knn2_hamming(const uint8_t* q, int nq, size_t q_stride,
+                      const uint8_t* t, int nt, size_t t_stride, int dbytes,
+                      int32_t* idx, float* dist, int threads);
+
+/* Same call site with NORM_L2 (squared == 0) or NORM_L2SQR (squared != 0):
+ * Source Files/feature_processing.cpp:111,115,121.  Strides are in floats. */
+void orc_knn2_l2(const float* q, int nq, size_t q_stride,
+                 const float* t, int nt, size_t t_stride, int dim, int squared,
+                 int32_t* idx, float* dist, int threads);
+
+/* The ratio filter of DescriptorMatcher::ratioMaches,
+ * Source Files/feature_processing.cpp:123-129.  Returns the match count;
+ * out has room for nq entries. */
+int orc_ratio_filter(const int32_t* idx, const float* dist, int nq, int nt,
+                     float ratio, orc_dmatch* out);
+
+/* The cross-check loop of DescriptorMatcher::findRobustMatches,
+ * Source Files/feature_processing.cpp:159-176.  Returns the match count;
+ * out has room for nb entries. */
+int orc_cross_check(const orc_dmatch* f, int nf, const orc_dmatch* b, int nb,
+                    orc_dmatch* out);
+
+/* ratioMaches both ways + cross-check, Source Files/feature_processing.cpp:
+ * 148-176 (the fundamental-matrix filter at :187-204 is not part of it).
+ * norm is one of ORC_NORM_*; d is bytes (Hamming) or floats (L2). Rows are
+ * contiguous.  Returns the match count; out has room for n_curr entries. */
+int orc_robust_matches(int norm, const void* prev, int n_prev,
+                       const void* curr, int n_curr, int d, float ratio,
+                       orc_dmatch* out, int threads);
+
+/* ---- pyramidal Lucas-Kanade -------------------------------------------- */
+
+/* cv::pyrDown, 8-bit single channel, BORDER_REFLECT_101, destination size
+ * ((w+1)/2, (h+1)/2); used by cv::buildOpticalFlowPyramid inside
+ * SparsePyrLKOpticalFlow::calc (Source Files/feature_processing.cpp:241). */
+void orc_pyr_down(const uint8_t* src, int w, int h, size_t src_stride,
+                  uint8_t* dst, size_t dst_stride);
+
+/* The Scharr derivative image of lkpyramid.cpp (calcSharrDeriv): interleaved
+ * int16 (Ix, Iy) per pixel, dst_stride in int16 elements. */
+void orc_scharr_deriv(const uint8_t* src, int w, int h, size_t src_stride,
+                      int16_t* dst, size_t dst_stride);
+
+/* Number of the top pyramid level cv::buildOpticalFlowPyramid keeps. */
+int orc_lk_num_levels(int w, int h, int win_w, int win_h, int max_level);
+
+/* OptFlow::computeFlow, Source Files/feature_processing.cpp:238-249:
+ * SparsePyrLKOpticalFlow::calc (flags 0) followed by status[i] = 0 where
+ * err[i] > max_error.  crit_type uses cv::TermCriteria bits (COUNT=1, EPS=2).
+ * acc_exact != 0 accumulates the normal-equation sums in int64 (exact)
+ * instead of OpenCV's float accumulators; everything else is identical.
+ * iters_out (nullable) receives the total number of LK iterations run. */
+void orc_pyrlk(const uint8_t* prev, const uint8_t* curr, int w, int h,
+               size_t stride, const float* prev_pts, int n, int win_w,
+               int win_h, int max_level, int crit_type, int max_count,
+               double epsilon, double min_eig_threshold, float max_error,
+               float* curr_pts, uint8_t* status, float* err, int acc_exact,
+               int threads, int64_t* iters_out);
+
+/* ---- triangulation ----------------------------------------------------- */
+
+/* Reconstruction::triangulateCloud + pointsToRGBCloud, Source Files/
+ * reconstruction.cpp:6-73.  K, R row-major 3x3; prev_pose/curr_pose row-major
+ * 3x4; pts are interleaved float (x, y).  bgr may be NULL (rgb then untouched).
+ * X is [n][3] double, rgb [n][3], mask [n], err (nullable) [n] double. */
+void orc_triangulate(const double* K, const double* prev_pose,
+                     const double* curr_pose, const double* R, const double* t,
+                     const float* prev_pts, const float* curr_pts, int n,
+                     const uint8_t* bgr, int img_w, int img_h, size_t img_stride,
+                     float min_dist, float max_dist, float max_proj_err,
+                     double* X, uint8_t* rgb, uint8_t* mask, double* err,
+                     int threads);
+
+/* Singular values (descending) and the right singular vector of the smallest
+ * one for a row-major 4x4 matrix: the one-sided Jacobi of cv::SVD::compute. */
+void orc_svd4_null(const double* A, double* w, double* v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,182 @@
+"""ctypes binding of oracle/liboracle.so, the CPU restatement of the hot path.
+
+TEST INFRASTRUCTURE ONLY.  Imported by tests/, by __graft_entry__.smoke() and by
+bench.py's cpu_baseline leg; never by the sfm_amd package.  Parity with OpenCV
+itself is unpinned (see oracle/oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+NORM_HAMMING, NORM_L2, NORM_L2SQR = 0, 1, 2
+
+DMATCH_DTYPE = np.dtype(
+    [("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")]
+)
+
+
+def build():
+    """Compile liboracle.so with the recipe in oracle/Makefile."""
+    subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_ratio_filter.restype = C.c_int
+        _lib.orc_cross_check.restype = C.c_int
+        _lib.orc_robust_matches.restype = C.c_int
+        _lib.orc_lk_num_levels.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def knn2_hamming(q, t, threads=0):
+    q = np.ascontiguousarray(q, dtype=np.uint8)
+    t = np.ascontiguousarray(t, dtype=np.uint8)
+    nq, d = q.shape
+    nt = t.shape[0]
+    idx = np.empty((nq, 2), np.int32)
+    dist = np.empty((nq, 2), np.float32)
+    lib().orc_knn2_hamming(_p(q), C.c_int(nq), C.c_size_t(d), _p(t), C.c_int(nt), C.c_size_t(d),
+                           C.c_int(d), _p(idx), _p(dist), C.c_int(threads))
+    return idx, dist
+
+
+def knn2_l2(q, t, squared=False, threads=0):
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    t = np.ascontiguousarray(t, dtype=np.float32)
+    nq, d = q.shape
+    nt = t.shape[0]
+    idx = np.empty((nq, 2), np.int32)
+    dist = np.empty((nq, 2), np.float32)
+    lib().orc_knn2_l2(_p(q), C.c_int(nq), C.c_size_t(d), _p(t), C.c_int(nt), C.c_size_t(d),
+                      C.c_int(d), C.c_int(1 if squared else 0), _p(idx), _p(dist),
+                      C.c_int(threads))
+    return idx, dist
+
+
+def ratio_filter(idx, dist, nt, ratio):
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    nq = idx.shape[0]
+    out = np.zeros(max(nq, 1), DMATCH_DTYPE)
+    n = lib().orc_ratio_filter(_p(idx), _p(dist), C.c_int(nq), C.c_int(nt), C.c_float(ratio),
+                               _p(out))
+    return out[:n].copy()
+
+
+def cross_check(f, b):
+    f = np.ascontiguousarray(f, dtype=DMATCH_DTYPE)
+    b = np.ascontiguousarray(b, dtype=DMATCH_DTYPE)
+    out = np.zeros(max(len(b), 1), DMATCH_DTYPE)
+    n = lib().orc_cross_check(_p(f), C.c_int(len(f)), _p(b), C.c_int(len(b)), _p(out))
+    return out[:n].copy()
+
+
+def robust_matches(norm, prev, curr, ratio, threads=0):
+    dt = np.uint8 if norm == NORM_HAMMING else np.float32
+    prev = np.ascontiguousarray(prev, dtype=dt)
+    curr = np.ascontiguousarray(curr, dtype=dt)
+    d = prev.shape[1] if prev.ndim == 2 else curr.shape[1]
+    out = np.zeros(max(len(curr), 1), DMATCH_DTYPE)
+    n = lib().orc_robust_matches(C.c_int(norm), _p(prev), C.c_int(len(prev)), _p(curr),
+                                 C.c_int(len(curr)), C.c_int(d), C.c_float(ratio), _p(out),
+                                 C.c_int(threads))
+    return out[:n].copy()
+
+
+def pyr_down(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    lib().orc_pyr_down(_p(img), C.c_int(w), C.c_int(h), C.c_size_t(img.strides[0]), _p(out),
+                       C.c_size_t(out.strides[0]))
+    return out
+
+
+def scharr_deriv(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.empty((h, w, 2), np.int16)
+    lib().orc_scharr_deriv(_p(img), C.c_int(w), C.c_int(h), C.c_size_t(img.strides[0]), _p(out),
+                           C.c_size_t(2 * w))
+    return out
+
+
+def lk_num_levels(w, h, win_w, win_h, max_level):
+    return lib().orc_lk_num_levels(C.c_int(w), C.c_int(h), C.c_int(win_w), C.c_int(win_h),
+                                   C.c_int(max_level))
+
+
+def pyrlk(prev, curr, prev_pts, win=(21, 21), max_level=3, crit_type=3, max_count=30,
+          epsilon=0.01, min_eig_threshold=1e-4, max_error=10.0, acc_exact=False, threads=0,
+          return_iters=False):
+    prev = np.ascontiguousarray(prev, dtype=np.uint8)
+    curr = np.ascontiguousarray(curr, dtype=np.uint8)
+    assert prev.shape == curr.shape and prev.ndim == 2
+    h, w = prev.shape
+    pts = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(-1, 2)
+    n = pts.shape[0]
+    out = np.zeros((n, 2), np.float32)
+    status = np.zeros(n, np.uint8)
+    err = np.zeros(n, np.float32)
+    iters = C.c_int64(0)
+    lib().orc_pyrlk(_p(prev), _p(curr), C.c_int(w), C.c_int(h), C.c_size_t(prev.strides[0]),
+                    _p(pts), C.c_int(n), C.c_int(win[0]), C.c_int(win[1]), C.c_int(max_level),
+                    C.c_int(crit_type), C.c_int(max_count), C.c_double(epsilon),
+                    C.c_double(min_eig_threshold), C.c_float(max_error), _p(out), _p(status),
+                    _p(err), C.c_int(1 if acc_exact else 0), C.c_int(threads), C.byref(iters))
+    if return_iters:
+        return out, status, err, iters.value
+    return out, status, err
+
+
+def triangulate(K, prev_pose, curr_pose, R, t, prev_pts, curr_pts, bgr=None, min_dist=1e-4,
+                max_dist=250.0, max_proj_err=3.0, threads=0):
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+    prev_pose = np.ascontiguousarray(prev_pose, dtype=np.float64).reshape(3, 4)
+    curr_pose = np.ascontiguousarray(curr_pose, dtype=np.float64).reshape(3, 4)
+    R = np.ascontiguousarray(R, dtype=np.float64).reshape(3, 3)
+    t = np.ascontiguousarray(t, dtype=np.float64).reshape(3)
+    p1 = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(curr_pts, dtype=np.float32).reshape(-1, 2)
+    n = p1.shape[0]
+    X = np.zeros((n, 3), np.float64)
+    rgb = np.zeros((n, 3), np.uint8)
+    mask = np.zeros(n, np.uint8)
+    err = np.zeros(n, np.float64)
+    if bgr is not None:
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        ih, iw = bgr.shape[:2]
+        bp, bs = _p(bgr), bgr.strides[0]
+    else:
+        ih = iw = 0
+        bp, bs = None, 0
+    lib().orc_triangulate(_p(K), _p(prev_pose), _p(curr_pose), _p(R), _p(t), _p(p1), _p(p2),
+                          C.c_int(n), bp, C.c_int(iw), C.c_int(ih), C.c_size_t(bs),
+                          C.c_float(min_dist), C.c_float(max_dist), C.c_float(max_proj_err),
+                          _p(X), _p(rgb), _p(mask), _p(err), C.c_int(threads))
+    return X, rgb, mask, err
+
+
+def svd4_null(A):
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(4, 4)
+    w = np.zeros(4)
+    v = np.zeros(4)
+    lib().orc_svd4_null(_p(A), _p(w), _p(v))
+    return w, v

@@ -1,0 +1,193 @@
+"""The C oracle (oracle/*.c) against the independently generated NumPy vectors
+in tests/golden/ (made by tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+def _as_tuples(m):
+    return [(int(a["queryIdx"]), int(a["trainIdx"]), float(a["distance"])) for a in m]
+
+
+@pytest.mark.parametrize("d", [32, 61, 64])
+def test_hamming_knn2_golden(oracle, d):
+    g = load_golden("hamming.npz")
+    for threads in (1, 0):
+        idx, dist = oracle.knn2_hamming(g[f"q{d}"], g[f"t{d}"], threads=threads)
+        np.testing.assert_array_equal(idx, g[f"idx{d}"])
+        np.testing.assert_array_equal(dist, g[f"dist{d}"])
+
+
+@pytest.mark.parametrize("nt", [1, 2, 3])
+def test_hamming_tiny_train(oracle, nt):
+    g = load_golden("hamming.npz")
+    idx, dist = oracle.knn2_hamming(g[f"tiny_q_nt{nt}"], g[f"tiny_t_nt{nt}"])
+    np.testing.assert_array_equal(idx, g[f"tiny_idx_nt{nt}"])
+    np.testing.assert_array_equal(dist, g[f"tiny_dist_nt{nt}"])
+
+
+@pytest.mark.parametrize("d", [32, 61, 64])
+@pytest.mark.parametrize("tag,ratio", [("r50", 0.5), ("r80", 0.8)])
+def test_ratio_and_cross_golden(oracle, d, tag, ratio):
+    g = load_golden("hamming.npz")
+    q, t = g[f"q{d}"], g[f"t{d}"]
+    idx, dist = oracle.knn2_hamming(q, t)
+    f = oracle.ratio_filter(idx, dist, len(t), ratio)
+    idxb, distb = oracle.knn2_hamming(t, q)
+    b = oracle.ratio_filter(idxb, distb, len(q), ratio)
+    assert _as_tuples(f) == [tuple(r) for r in g[f"fwd{d}_{tag}"].tolist()]
+    assert _as_tuples(b) == [tuple(r) for r in g[f"bwd{d}_{tag}"].tolist()]
+    x = oracle.cross_check(f, b)
+    want = [tuple(r) for r in g[f"cross{d}_{tag}"].tolist()]
+    assert _as_tuples(x) == want
+    # the O(n) restatement used by the timed baseline gives the same list
+    x2 = oracle.robust_matches(oracle.NORM_HAMMING, q, t, ratio)
+    assert _as_tuples(x2) == want
+    if tag == "r80":
+        assert len(want) > 10  # the fixture is not vacuous
+
+
+def test_ratio_needs_two_train_rows(oracle):
+    g = load_golden("hamming.npz")
+    idx, dist = oracle.knn2_hamming(g["tiny_q_nt1"], g["tiny_t_nt1"])
+    assert len(oracle.ratio_filter(idx, dist, 1, 0.9)) == 0
+    assert len(oracle.robust_matches(oracle.NORM_HAMMING, g["tiny_q_nt1"], g["tiny_t_nt1"], 0.9)) == 0
+
+
+def test_l2_integer_valued_golden(oracle):
+    g = load_golden("l2.npz")
+    idx, dist = oracle.knn2_l2(g["int_q"], g["int_t"], squared=True)
+    np.testing.assert_array_equal(idx, g["int_idx"])
+    np.testing.assert_array_equal(dist, g["int_sqr"])
+    idx, dist = oracle.knn2_l2(g["int_q"], g["int_t"], squared=False)
+    np.testing.assert_array_equal(idx, g["int_idx_l2"])
+    np.testing.assert_array_equal(dist, g["int_l2"])
+
+
+def test_l2_real_valued_golden(oracle):
+    g = load_golden("l2.npz")
+    idx, dist = oracle.knn2_l2(g["real_q"], g["real_t"], squared=True)
+    d64 = g["real_sqr64"]
+    # float32 accumulation error for unit-norm rows is ~1e-6; require index
+    # agreement where the float64 gaps are clear of that
+    clear = (d64[:, 1] - d64[:, 0] > 1e-5) & (d64[:, 2] - d64[:, 1] > 1e-5)
+    assert clear.sum() > 50
+    np.testing.assert_array_equal(idx[clear], g["real_idx"][clear])
+    np.testing.assert_allclose(dist, d64[:, :2], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_pyr_down_golden(oracle, name):
+    g = load_golden("lk.npz")
+    np.testing.assert_array_equal(oracle.pyr_down(g[f"pyr_src_{name}"]), g[f"pyr_dst_{name}"])
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_scharr_golden(oracle, name):
+    g = load_golden("lk.npz")
+    np.testing.assert_array_equal(oracle.scharr_deriv(g[f"pyr_src_{name}"]), g[f"scharr_{name}"])
+
+
+@pytest.mark.parametrize("exact", [0, 1])
+def test_pyrlk_golden(oracle, exact):
+    g = load_golden("lk.npz")
+    assert oracle.lk_num_levels(64, 48, 9, 9, 3) == int(g["lk_levels"][0]) == 2
+    for threads in (1, 0):
+        nxt, st, err = oracle.pyrlk(g["lk_prev"], g["lk_curr"], g["lk_pts"], win=(9, 9),
+                                    max_level=3, crit_type=3, max_count=30, epsilon=0.01,
+                                    acc_exact=bool(exact), threads=threads)
+        np.testing.assert_array_equal(st, g[f"lk_status_{exact}"])
+        np.testing.assert_array_equal(nxt, g[f"lk_next_{exact}"])
+        np.testing.assert_array_equal(err, g[f"lk_err_{exact}"])
+    # known answer: tracked points moved by the image shift
+    ok = st.astype(bool)
+    assert ok.sum() >= 20
+    d = (nxt - g["lk_pts"])[ok]
+    assert np.abs(np.median(d, axis=0) - g["lk_shift"]).max() < 0.1
+
+
+def test_pyrlk_second_config_golden(oracle):
+    g = load_golden("lk.npz")
+    nxt, st, err = oracle.pyrlk(g["lk_prev"], g["lk_curr"], g["lk_pts"], win=(7, 5), max_level=1,
+                                crit_type=3, max_count=10, epsilon=0.0, acc_exact=True)
+    np.testing.assert_array_equal(st, g["lk2_status"])
+    np.testing.assert_array_equal(nxt, g["lk2_next"])
+    np.testing.assert_array_equal(err, g["lk2_err"])
+
+
+def test_pyrlk_identical_images(oracle):
+    g = load_golden("lk.npz")
+    pts = g["lk_pts"][:30]
+    nxt, st, err = oracle.pyrlk(g["lk_prev"], g["lk_prev"], pts, win=(9, 9), acc_exact=True)
+    assert st.all()
+    # (x - halfWin) + halfWin may round by an ulp; the flow itself is exactly zero
+    np.testing.assert_allclose(nxt, pts, rtol=0, atol=4e-6)
+    np.testing.assert_array_equal(err, np.zeros(len(pts), np.float32))
+
+
+def test_float_and_exact_accumulators_agree(oracle):
+    g = load_golden("lk.npz")
+    a = g["lk_next_0"]
+    b = g["lk_next_1"]
+    ok = g["lk_status_0"].astype(bool) & g["lk_status_1"].astype(bool)
+    assert np.abs(a[ok] - b[ok]).max() < 1e-3
+
+
+def test_svd4_golden(oracle):
+    g = load_golden("svd4.npz")
+    for A, w, v in zip(g["A"], g["w"], g["v"]):
+        ww, vv = oracle.svd4_null(A)
+        np.testing.assert_allclose(ww, w, rtol=1e-12)
+        s = np.sign(np.dot(vv, v))
+        np.testing.assert_allclose(vv * s, v, atol=1e-9)
+
+
+def test_triangulate_golden(oracle):
+    g = load_golden("triangulate.npz")
+    img = np.random.default_rng(int(g["img_seed"][0]))
+    # the generator drew the image after the point data; regenerate the same stream
+    X, rgb, mask, err = oracle.triangulate(g["K"], g["prev_pose"], g["curr_pose"], g["R"], g["t"],
+                                           g["p1"], g["p2"])
+    sv = g["sv"]
+    well = sv[:, 3] / sv[:, 2] < 0.5  # smallest singular value separated from the next
+    assert well.sum() > 380
+    rel = np.linalg.norm(X - g["X"], axis=1) / np.linalg.norm(g["X"], axis=1)
+    assert rel[well].max() < 1e-8
+    np.testing.assert_allclose(err[well], g["err"][well], rtol=1e-6, atol=1e-7)
+    # mask agrees wherever no threshold is within a hair of the value
+    band = (np.abs(g["err"] - 3.0) < 1e-6) | (np.abs(g["depth"] - 250.0) < 1e-6)
+    np.testing.assert_array_equal(mask[well & ~band], g["mask"][well & ~band])
+    assert 0 < mask.sum() < len(mask)
+    # known answer: noise-free projections of the generating points come back
+    del img
+
+
+def test_triangulate_exact_projections(oracle):
+    g = load_golden("triangulate.npz")
+    K, Rm, t = g["K"], g["R"], g["t"]
+    Xw = g["truth"][:100]
+    P1 = K @ g["prev_pose"]
+    P2 = K @ g["curr_pose"]
+    h = np.hstack([Xw, np.ones((len(Xw), 1))])
+    p1 = (P1 @ h.T).T
+    p2 = (P2 @ h.T).T
+    p1 = (p1[:, :2] / p1[:, 2:]).astype(np.float32)
+    p2 = (p2[:, :2] / p2[:, 2:]).astype(np.float32)
+    X, _, mask, err = oracle.triangulate(K, g["prev_pose"], g["curr_pose"], Rm, t, p1, p2)
+    # float32 pixel coordinates limit the accuracy (~1e-4 px at 1000 px)
+    rel = np.linalg.norm(X - Xw, axis=1) / np.linalg.norm(Xw, axis=1)
+    assert rel.max() < 5e-3
+    assert mask.all()
+    assert err.max() < 1e-2
+
+
+def test_triangulate_colour_lookup(oracle):
+    g = load_golden("triangulate.npz")
+    rng = np.random.default_rng(123)
+    img = rng.integers(0, 256, size=(720, 1280, 3), dtype=np.uint8)
+    _, rgb, _, _ = oracle.triangulate(g["K"], g["prev_pose"], g["curr_pose"], g["R"], g["t"],
+                                      g["p1"], g["p2"], bgr=img)
+    px = np.clip(np.rint(g["p2"][:, 0].astype(np.float64)).astype(int), 0, 1279)
+    py = np.clip(np.rint(g["p2"][:, 1].astype(np.float64)).astype(int), 0, 719)
+    np.testing.assert_array_equal(rgb, img[py, px])
