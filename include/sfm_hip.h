@@ -1,0 +1,187 @@
+/*
+ * sfm_hip.h -- C ABI of the MI355X (gfx950) implementation of the Lowcash/SfM
+ * per-frame hot path: descriptor matching, pyramidal Lucas-Kanade tracking and
+ * two-view DLT triangulation with reprojection filtering.
+ *
+ * Every entry point replaces one call the reference makes into OpenCV from its
+ * wrapper layer; the reference location is cited as
+ * "<reference file>:<line>" (paths relative to the reference tree, whose source
+ * directories are "Source Files/" and "Header Files/").
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  No exceptions cross this boundary.
+ *   - Every function returns 0 on success, a negative SFM_E_* code otherwise;
+ *     sfm_last_error() then describes the failure.
+ *   - Functions without a suffix take HOST pointers: they copy inputs to the
+ *     GPU, run, copy results back and return when the results are in place.
+ *   - Functions ending in _dev take DEVICE pointers, enqueue their work on the
+ *     context's stream and return without synchronising; inputs and outputs
+ *     must stay valid until sfm_ctx_synchronize() (or the caller's own stream
+ *     synchronisation) has returned.
+ *   - A context is not thread-safe; use one context per host thread.  The
+ *     reference calls this path from its single main-loop thread
+ *     (Source Files/app_solver.cpp:151).
+ */
+#ifndef SFM_HIP_H
+#define SFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_OK 0
+#define SFM_E_INVALID (-1)   /* bad argument */
+#define SFM_E_HIP (-2)       /* a HIP runtime call failed */
+#define SFM_E_NOMEM (-3)     /* device or host allocation failed */
+#define SFM_E_UNSUPPORTED (-4)
+
+/* cv::NormTypes the reference selects in DescriptorMatcher::DescriptorMatcher,
+ * Source Files/feature_processing.cpp:108-115. */
+#define SFM_NORM_HAMMING 0 /* "BRUTEFORCE_HAMMING" */
+#define SFM_NORM_L2 1      /* "BRUTEFORCE" (the default branch) */
+#define SFM_NORM_L2SQR 2   /* "BRUTEFORCE_SL2" */
+
+/* cv::TermCriteria type bits (Source Files/app_solver.cpp:108). */
+#define SFM_TERM_COUNT 1
+#define SFM_TERM_EPS 2
+
+/* Same memory layout as cv::DMatch (16 bytes). */
+typedef struct sfm_dmatch {
+    int32_t queryIdx;
+    int32_t trainIdx;
+    int32_t imgIdx;
+    float distance;
+} sfm_dmatch;
+
+typedef struct sfm_ctx sfm_ctx;
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Creates a context on HIP device `device` with a stream of its own. */
+int sfm_ctx_create(int device, sfm_ctx** out);
+/* As above but enqueues on the caller's hipStream_t (not owned). */
+int sfm_ctx_create_on_stream(int device, void* hip_stream, sfm_ctx** out);
+void sfm_ctx_destroy(sfm_ctx* ctx);
+int sfm_ctx_synchronize(sfm_ctx* ctx);
+/* Grows the context's device workspace to at least `bytes` so that later _dev
+ * calls needing no more than that do not allocate. */
+int sfm_ctx_reserve(sfm_ctx* ctx, size_t bytes);
+/* Message of the last failure on this context (or of the last failed
+ * sfm_ctx_create when ctx is NULL).  Never NULL. */
+const char* sfm_last_error(const sfm_ctx* ctx);
+/* "sfm_hip <version> gfx950" */
+const char* sfm_version(void);
+
+/* ---- descriptor matching ------------------------------------------------ */
+
+/* Brute-force 2-nearest-neighbour search: replaces
+ * matcher->knnMatch(lDesc, rDesc, knnMatches, 2), Source Files/
+ * feature_processing.cpp:121.  `norm` is SFM_NORM_*.  For SFM_NORM_HAMMING rows
+ * are `d` bytes of CV_8U and strides are in bytes; for the L2 norms rows are
+ * `d` floats and strides are in bytes too.  idx and dist are [nq][2]; equal
+ * distances keep the lower train index first; a slot without a neighbour
+ * (nt < 2) holds idx -1 and dist FLT_MAX.  nt must be below 2^18 (OpenCV's own
+ * limit for one train image). */
+int sfm_knn2(sfm_ctx* ctx, int norm, const void* q, int nq, size_t q_stride,
+             const void* t, int nt, size_t t_stride, int d, int32_t* idx, float* dist);
+int sfm_knn2_dev(sfm_ctx* ctx, int norm, const void* d_q, int nq, size_t q_stride,
+                 const void* d_t, int nt, size_t t_stride, int d, int32_t* d_idx,
+                 float* d_dist);
+
+/* DescriptorMatcher::ratioMaches, Source Files/feature_processing.cpp:118-130:
+ * 2-NN followed by  k[0].distance < ratio * k[1].distance.  out has room for nq
+ * matches in ascending queryIdx order; *out_count receives their number.  A
+ * train set with fewer than two rows yields no match (the reference reads k[1]
+ * out of bounds there). */
+int sfm_ratio_matches(sfm_ctx* ctx, int norm, const void* q, int nq, size_t q_stride,
+                      const void* t, int nt, size_t t_stride, int d, float ratio,
+                      sfm_dmatch* out, int* out_count);
+
+/* DescriptorMatcher::findRobustMatches up to and including the cross-check,
+ * Source Files/feature_processing.cpp:148-176: ratio matches prev->curr and
+ * curr->prev, then every backward match whose forward counterpart agrees, in
+ * the order of the backward list (ascending curr index).  out has room for
+ * min(n_prev, n_curr) matches (queryIdx = prev row, trainIdx = curr row). */
+int sfm_robust_matches(sfm_ctx* ctx, int norm, const void* prev, int n_prev,
+                       size_t prev_stride, const void* curr, int n_curr, size_t curr_stride,
+                       int d, float ratio, sfm_dmatch* out, int* out_count);
+
+/* The same over many frame pairs in one launch sequence (the reference runs
+ * it once per pair: Source Files/app_solver.cpp:404, Source Files/
+ * tracking.cpp:135).  d_desc holds n_frames descriptor blocks, block f at
+ * d_desc + f*frame_stride bytes, rows contiguous (`d` bytes or floats each);
+ * d_counts[f] (device, may be NULL = rows_per_frame for all) is the row count of
+ * frame f.  d_pairs is a device array of n_pairs (prev_frame, curr_frame)
+ * int32 pairs.  Pair p writes up to `cap` matches at d_matches + p*cap and its
+ * match count at d_match_counts[p] (the count is not clipped to cap). */
+int sfm_match_pairs_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames,
+                        size_t frame_stride, int rows_per_frame, const int32_t* d_counts,
+                        int d, const int32_t* d_pairs, int n_pairs, float ratio,
+                        sfm_dmatch* d_matches, int cap, int32_t* d_match_counts);
+/* Workspace bytes sfm_match_pairs_dev needs for these sizes. */
+size_t sfm_match_pairs_workspace(int norm, int rows_per_frame, int d, int n_pairs);
+
+/* ---- pyramidal Lucas-Kanade --------------------------------------------- */
+
+/* OptFlow::computeFlow, Source Files/feature_processing.cpp:238-249:
+ * cv::SparsePyrLKOpticalFlow::calc with flags 0 on two 8-bit single-channel
+ * images, then status[i] = 0 where err[i] > max_error.  The tracker settings
+ * are those OptFlow::OptFlow hands to SparsePyrLKOpticalFlow::create
+ * (Source Files/feature_processing.cpp:228-236): window, max_level, the term
+ * criteria (clamped as OpenCV does: count to [0,100], epsilon to [0,10]) and
+ * OpenCV's default minEigThreshold 1e-4.  Points are interleaved (x, y) floats.
+ * err (may be NULL) receives the per-point residual.  The normal-equation sums
+ * are accumulated exactly in integers (OpenCV: float, build-dependent order).
+ * Windows up to 41x41 are supported. */
+int sfm_pyrlk(sfm_ctx* ctx, const uint8_t* prev, const uint8_t* curr, int width, int height,
+              size_t stride, const float* prev_pts, int n, int win_w, int win_h,
+              int max_level, int crit_type, int max_count, double epsilon,
+              double min_eig_threshold, float max_error, float* curr_pts, uint8_t* status,
+              float* err);
+
+/* Batched device form: n_pairs image pairs, pair p at d_prev + p*image_stride /
+ * d_curr + p*image_stride (rows `stride` bytes apart), n points per pair at
+ * d_prev_pts + p*n*2.  Outputs are laid out likewise. */
+int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_curr,
+                        int n_pairs, size_t image_stride, int width, int height,
+                        size_t stride, const float* d_prev_pts, int n, int win_w, int win_h,
+                        int max_level, int crit_type, int max_count, double epsilon,
+                        double min_eig_threshold, float max_error, float* d_curr_pts,
+                        uint8_t* d_status, float* d_err);
+size_t sfm_pyrlk_workspace(int n_pairs, int width, int height, int win_w, int win_h,
+                           int max_level);
+
+/* ---- triangulation ------------------------------------------------------ */
+
+/* Reconstruction::triangulateCloud with pointsToRGBCloud, Source Files/
+ * reconstruction.cpp:41-73 and :6-39: cv::triangulatePoints(K*prev_pose,
+ * K*curr_pose, ...) per correspondence (4x4 homogeneous system, right singular
+ * vector of the smallest singular value, divided by w), then reprojection with
+ * the separately supplied R, t, and
+ *   mask = err < max_proj_err && depth > min_dist && depth < max_dist.
+ * K and R are row-major 3x3, poses row-major 3x4, t has 3 entries, points are
+ * interleaved (x, y) floats.  X is [n][3] doubles.  bgr (may be NULL) is the
+ * 8-bit 3-channel image colours are read from at round(curr point), clamped to
+ * the image (the reference does not check bounds); rgb is [n][3] and untouched
+ * when bgr is NULL.  err (may be NULL) receives the reprojection error. */
+int sfm_triangulate(sfm_ctx* ctx, const double* K, const double* prev_pose,
+                    const double* curr_pose, const double* R, const double* t,
+                    const float* prev_pts, const float* curr_pts, int n, const uint8_t* bgr,
+                    int img_w, int img_h, size_t img_stride, float min_dist, float max_dist,
+                    float max_proj_err, double* X, uint8_t* rgb, uint8_t* mask, double* err);
+/* Device form: the five small matrices stay host pointers (they travel as
+ * kernel arguments); points, image and outputs are device pointers. */
+int sfm_triangulate_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
+                        const double* curr_pose, const double* R, const double* t,
+                        const float* d_prev_pts, const float* d_curr_pts, int n,
+                        const uint8_t* d_bgr, int img_w, int img_h, size_t img_stride,
+                        float min_dist, float max_dist, float max_proj_err, double* d_X,
+                        uint8_t* d_rgb, uint8_t* d_mask, double* d_err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFM_HIP_H */

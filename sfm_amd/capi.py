@@ -1,0 +1,261 @@
+"""ctypes binding of the C ABI in include/sfm_hip.h (sfm_amd/lib/libsfm_hip.so).
+
+torch is imported before the library is loaded so that both share one HIP
+runtime in the process (torch's bundled libamdhip64 has the same soname as the
+system one the library was linked against).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+try:  # the library itself does not need torch; sharing its HIP runtime does
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsfm_hip.so")
+
+NORM_HAMMING, NORM_L2, NORM_L2SQR = 0, 1, 2
+TERM_COUNT, TERM_EPS = 1, 2
+
+DMATCH_DTYPE = np.dtype(
+    [("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")]
+)
+
+# every symbol include/sfm_hip.h declares
+EXPORTS = [
+    "sfm_ctx_create", "sfm_ctx_create_on_stream", "sfm_ctx_destroy", "sfm_ctx_synchronize",
+    "sfm_ctx_reserve", "sfm_last_error", "sfm_version",
+    "sfm_knn2", "sfm_knn2_dev", "sfm_ratio_matches", "sfm_robust_matches",
+    "sfm_match_pairs_dev", "sfm_match_pairs_workspace",
+    "sfm_pyrlk", "sfm_pyrlk_batch_dev", "sfm_pyrlk_workspace",
+    "sfm_triangulate", "sfm_triangulate_dev",
+]
+
+
+class SfmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libsfm_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SfmError(
+                f"{LIB_PATH} is missing: build it with `make -C sfm_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        l.sfm_last_error.restype = C.c_char_p
+        l.sfm_last_error.argtypes = [C.c_void_p]
+        l.sfm_version.restype = C.c_char_p
+        l.sfm_ctx_destroy.restype = None
+        l.sfm_ctx_destroy.argtypes = [C.c_void_p]
+        for name in ("sfm_match_pairs_workspace", "sfm_pyrlk_workspace"):
+            if hasattr(l, name):
+                getattr(l, name).restype = C.c_size_t
+        _lib = l
+    return _lib
+
+
+def _ptr(a):
+    """void* of a numpy array, a torch tensor, an int address or None."""
+    if a is None:
+        return C.c_void_p(None)
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return C.c_void_p(a.data_ptr())
+
+
+class Context:
+    """An sfm_ctx: a device, a stream and the library's device workspace."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p(None)
+        l = lib()
+        if stream is None:
+            rc = l.sfm_ctx_create(C.c_int(device), C.byref(self._h))
+        else:
+            rc = l.sfm_ctx_create_on_stream(C.c_int(device), C.c_void_p(int(stream)),
+                                            C.byref(self._h))
+        if rc != 0:
+            raise SfmError(l.sfm_last_error(None).decode())
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().sfm_ctx_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise SfmError(f"[{rc}] " + lib().sfm_last_error(self._h).decode())
+
+    def synchronize(self):
+        self.check(lib().sfm_ctx_synchronize(self._h))
+
+    def reserve(self, nbytes):
+        self.check(lib().sfm_ctx_reserve(self._h, C.c_size_t(nbytes)))
+
+    # ---- matching ---------------------------------------------------------
+    @staticmethod
+    def _desc(norm, a):
+        dt = np.uint8 if norm == NORM_HAMMING else np.float32
+        a = np.ascontiguousarray(a, dtype=dt)
+        if a.ndim != 2:
+            raise ValueError("descriptors must be a 2-D array (rows x length)")
+        return a
+
+    def knn2(self, norm, q, t):
+        q, t = self._desc(norm, q), self._desc(norm, t)
+        nq, d = q.shape
+        nt = t.shape[0]
+        if nt and t.shape[1] != d:
+            raise ValueError("query and train descriptors differ in length")
+        idx = np.full((nq, 2), -1, np.int32)
+        dist = np.full((nq, 2), np.finfo(np.float32).max, np.float32)
+        self.check(lib().sfm_knn2(self._h, C.c_int(norm), _ptr(q), C.c_int(nq),
+                                  C.c_size_t(q.strides[0]), _ptr(t), C.c_int(nt),
+                                  C.c_size_t(t.strides[0] if nt else d * q.itemsize), C.c_int(d),
+                                  _ptr(idx), _ptr(dist)))
+        return idx, dist
+
+    def knn2_dev(self, norm, d_q, nq, q_stride, d_t, nt, t_stride, d, d_idx, d_dist):
+        self.check(lib().sfm_knn2_dev(self._h, C.c_int(norm), _ptr(d_q), C.c_int(nq),
+                                      C.c_size_t(q_stride), _ptr(d_t), C.c_int(nt),
+                                      C.c_size_t(t_stride), C.c_int(d), _ptr(d_idx),
+                                      _ptr(d_dist)))
+
+    def ratio_matches(self, norm, q, t, ratio):
+        q, t = self._desc(norm, q), self._desc(norm, t)
+        nq, d = q.shape
+        nt = t.shape[0]
+        out = np.zeros(max(nq, 1), DMATCH_DTYPE)
+        cnt = C.c_int(0)
+        self.check(lib().sfm_ratio_matches(self._h, C.c_int(norm), _ptr(q), C.c_int(nq),
+                                           C.c_size_t(q.strides[0]), _ptr(t), C.c_int(nt),
+                                           C.c_size_t(t.strides[0] if nt else d * q.itemsize),
+                                           C.c_int(d), C.c_float(ratio), _ptr(out),
+                                           C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def robust_matches(self, norm, prev, curr, ratio):
+        prev, curr = self._desc(norm, prev), self._desc(norm, curr)
+        n_prev, n_curr = prev.shape[0], curr.shape[0]
+        d = prev.shape[1] if n_prev else curr.shape[1]
+        out = np.zeros(max(min(n_prev, n_curr), 1), DMATCH_DTYPE)
+        cnt = C.c_int(0)
+        self.check(lib().sfm_robust_matches(
+            self._h, C.c_int(norm), _ptr(prev), C.c_int(n_prev),
+            C.c_size_t(prev.strides[0] if n_prev else d * prev.itemsize), _ptr(curr),
+            C.c_int(n_curr), C.c_size_t(curr.strides[0] if n_curr else d * curr.itemsize),
+            C.c_int(d), C.c_float(ratio), _ptr(out), C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def match_pairs_dev(self, norm, d_desc, n_frames, frame_stride, rows_per_frame, d_counts, d,
+                        d_pairs, n_pairs, ratio, d_matches, cap, d_match_counts):
+        self.check(lib().sfm_match_pairs_dev(
+            self._h, C.c_int(norm), _ptr(d_desc), C.c_int(n_frames), C.c_size_t(frame_stride),
+            C.c_int(rows_per_frame), _ptr(d_counts), C.c_int(d), _ptr(d_pairs), C.c_int(n_pairs),
+            C.c_float(ratio), _ptr(d_matches), C.c_int(cap), _ptr(d_match_counts)))
+
+    @staticmethod
+    def match_pairs_workspace(norm, rows_per_frame, d, n_pairs):
+        return int(lib().sfm_match_pairs_workspace(C.c_int(norm), C.c_int(rows_per_frame),
+                                                   C.c_int(d), C.c_int(n_pairs)))
+
+    # ---- Lucas-Kanade -----------------------------------------------------
+    def pyrlk(self, prev, curr, prev_pts, win=(21, 21), max_level=3,
+              crit_type=TERM_COUNT | TERM_EPS, max_count=30, epsilon=0.01,
+              min_eig_threshold=1e-4, max_error=10.0):
+        prev = np.ascontiguousarray(prev, dtype=np.uint8)
+        curr = np.ascontiguousarray(curr, dtype=np.uint8)
+        if prev.ndim != 2 or prev.shape != curr.shape:
+            raise ValueError("images must be equal-size 8-bit single-channel arrays")
+        h, w = prev.shape
+        pts = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(-1, 2)
+        n = pts.shape[0]
+        out = np.zeros((n, 2), np.float32)
+        status = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float32)
+        self.check(lib().sfm_pyrlk(
+            self._h, _ptr(prev), _ptr(curr), C.c_int(w), C.c_int(h), C.c_size_t(prev.strides[0]),
+            _ptr(pts), C.c_int(n), C.c_int(win[0]), C.c_int(win[1]), C.c_int(max_level),
+            C.c_int(crit_type), C.c_int(max_count), C.c_double(epsilon),
+            C.c_double(min_eig_threshold), C.c_float(max_error), _ptr(out), _ptr(status),
+            _ptr(err)))
+        return out, status, err
+
+    def pyrlk_batch_dev(self, d_prev, d_curr, n_pairs, image_stride, width, height, stride,
+                        d_prev_pts, n, win, max_level, crit_type, max_count, epsilon,
+                        min_eig_threshold, max_error, d_curr_pts, d_status, d_err):
+        self.check(lib().sfm_pyrlk_batch_dev(
+            self._h, _ptr(d_prev), _ptr(d_curr), C.c_int(n_pairs), C.c_size_t(image_stride),
+            C.c_int(width), C.c_int(height), C.c_size_t(stride), _ptr(d_prev_pts), C.c_int(n),
+            C.c_int(win[0]), C.c_int(win[1]), C.c_int(max_level), C.c_int(crit_type),
+            C.c_int(max_count), C.c_double(epsilon), C.c_double(min_eig_threshold),
+            C.c_float(max_error), _ptr(d_curr_pts), _ptr(d_status), _ptr(d_err)))
+
+    @staticmethod
+    def pyrlk_workspace(n_pairs, width, height, win, max_level):
+        return int(lib().sfm_pyrlk_workspace(C.c_int(n_pairs), C.c_int(width), C.c_int(height),
+                                             C.c_int(win[0]), C.c_int(win[1]),
+                                             C.c_int(max_level)))
+
+    # ---- triangulation ----------------------------------------------------
+    @staticmethod
+    def _mats(K, prev_pose, curr_pose, R, t):
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+        prev_pose = np.ascontiguousarray(prev_pose, dtype=np.float64).reshape(3, 4)
+        curr_pose = np.ascontiguousarray(curr_pose, dtype=np.float64).reshape(3, 4)
+        R = np.ascontiguousarray(R, dtype=np.float64).reshape(3, 3)
+        t = np.ascontiguousarray(t, dtype=np.float64).reshape(3)
+        return K, prev_pose, curr_pose, R, t
+
+    def triangulate(self, K, prev_pose, curr_pose, R, t, prev_pts, curr_pts, bgr=None,
+                    min_dist=1e-4, max_dist=250.0, max_proj_err=3.0):
+        K, prev_pose, curr_pose, R, t = self._mats(K, prev_pose, curr_pose, R, t)
+        p1 = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(curr_pts, dtype=np.float32).reshape(-1, 2)
+        if p1.shape != p2.shape:
+            raise ValueError("prev and curr point lists differ in length")
+        n = p1.shape[0]
+        X = np.zeros((n, 3), np.float64)
+        rgb = np.zeros((n, 3), np.uint8)
+        mask = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float64)
+        if bgr is not None:
+            bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+            ih, iw = bgr.shape[:2]
+            bs = bgr.strides[0]
+        else:
+            ih = iw = bs = 0
+        self.check(lib().sfm_triangulate(
+            self._h, _ptr(K), _ptr(prev_pose), _ptr(curr_pose), _ptr(R), _ptr(t), _ptr(p1),
+            _ptr(p2), C.c_int(n), _ptr(bgr), C.c_int(iw), C.c_int(ih), C.c_size_t(bs),
+            C.c_float(min_dist), C.c_float(max_dist), C.c_float(max_proj_err), _ptr(X), _ptr(rgb),
+            _ptr(mask), _ptr(err)))
+        return X, rgb, mask, err
+
+    def triangulate_dev(self, K, prev_pose, curr_pose, R, t, d_prev_pts, d_curr_pts, n, d_bgr,
+                        img_w, img_h, img_stride, min_dist, max_dist, max_proj_err, d_X, d_rgb,
+                        d_mask, d_err=None):
+        K, prev_pose, curr_pose, R, t = self._mats(K, prev_pose, curr_pose, R, t)
+        self.check(lib().sfm_triangulate_dev(
+            self._h, _ptr(K), _ptr(prev_pose), _ptr(curr_pose), _ptr(R), _ptr(t),
+            _ptr(d_prev_pts), _ptr(d_curr_pts), C.c_int(n), _ptr(d_bgr), C.c_int(img_w),
+            C.c_int(img_h), C.c_size_t(img_stride), C.c_float(min_dist), C.c_float(max_dist),
+            C.c_float(max_proj_err), _ptr(d_X), _ptr(d_rgb), _ptr(d_mask), _ptr(d_err)))

@@ -1,0 +1,331 @@
+// extern "C" entry points of the descriptor-matching stage (see include/sfm_hip.h).
+#include <algorithm>
+#include <cfloat>
+#include <vector>
+
+#include "sfm_internal.h"
+
+namespace sfm {
+int launch_ratio_compact(sfm_ctx* ctx, const int32_t* d_idx, const float* d_dist, int nq, int nt,
+                         float ratio, sfm_dmatch* d_out, int32_t* d_count);
+int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_stride,
+                const float* d_t, int nt, size_t t_stride, int dim, int32_t* d_idx, float* d_dist);
+int l2_match_pairs_dev(sfm_ctx* ctx, int squared, const float* d_desc, size_t frame_stride,
+                       int rows_per_frame, const int32_t* d_counts, int dim,
+                       const int32_t* d_pairs, int n_pairs, float ratio, sfm_dmatch* d_matches,
+                       int cap, int32_t* d_match_counts);
+size_t l2_match_pairs_workspace(int rows_per_frame, int dim, int n_pairs);
+}  // namespace sfm
+
+using namespace sfm;
+
+namespace {
+
+constexpr int kMaxTrainRows = 1 << 18;
+constexpr int kMaxHammingBytes = 256;
+// Pairs handled per launch sequence: bounds the key workspace (2 problems per
+// pair, 8 bytes per query row and split).
+constexpr int kPairChunk = 4096;
+
+int check_common(sfm_ctx* ctx, int norm, int n_a, int n_b, int d) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (norm != SFM_NORM_HAMMING && norm != SFM_NORM_L2 && norm != SFM_NORM_L2SQR)
+        return set_error(ctx, SFM_E_INVALID, "unknown norm %d", norm);
+    if (n_a < 0 || n_b < 0) return set_error(ctx, SFM_E_INVALID, "negative row count");
+    if (n_a >= kMaxTrainRows || n_b >= kMaxTrainRows)
+        return set_error(ctx, SFM_E_INVALID, "row count must be below 2^18");
+    if (d <= 0) return set_error(ctx, SFM_E_INVALID, "descriptor length must be positive");
+    if (norm == SFM_NORM_HAMMING && d > kMaxHammingBytes)
+        return set_error(ctx, SFM_E_UNSUPPORTED, "Hamming descriptors above %d bytes unsupported",
+                         kMaxHammingBytes);
+    return SFM_OK;
+}
+
+bool is_packed(const void* p, size_t stride, int d, int row_words) {
+    return d == row_words * 4 && stride == (size_t)d && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+
+// Hamming robust matching over frames already packed to plan.row_words words per
+// row.  Workspace is carved from `c`.
+int hamming_pairs_packed(sfm_ctx* ctx, const KnnPlan& plan, const void* packed, size_t frame_stride,
+                         int rows_uniform, const int32_t* d_counts, const int32_t* d_pairs,
+                         int n_pairs, float ratio, sfm_dmatch* d_matches, int cap,
+                         int32_t* d_match_counts, Carver& c) {
+    const size_t nprob = 2 * (size_t)n_pairs;
+    uint32_t* keys = c.take<uint32_t>(nprob * plan.splits * plan.rows_max * 2);
+    int32_t* best = c.take<int32_t>(nprob * plan.rows_max);
+    float* best_dist = c.take<float>(nprob * plan.rows_max);
+    KnnBatch b{};
+    b.q_base = b.t_base = packed;
+    b.q_frame_stride = b.t_frame_stride = frame_stride;
+    b.d_counts_q = b.d_counts_t = d_counts;
+    b.nq_uniform = b.nt_uniform = rows_uniform;
+    b.d_pairs = d_pairs;
+    b.n_problems = (int)nprob;
+    SFM_RETURN_IF(launch_hamming_knn2(ctx, plan, b, keys));
+    return launch_ratio_cross(ctx, plan, keys, d_counts, rows_uniform, rows_uniform, d_pairs,
+                              n_pairs, ratio, best, best_dist, d_matches, cap, d_match_counts);
+}
+
+size_t hamming_pairs_bytes(const KnnPlan& plan, int n_pairs) {
+    Carver c(nullptr);
+    const size_t nprob = 2 * (size_t)n_pairs;
+    c.take<uint32_t>(nprob * plan.splits * plan.rows_max * 2);
+    c.take<int32_t>(nprob * plan.rows_max);
+    c.take<float>(nprob * plan.rows_max);
+    return c.total();
+}
+
+}  // namespace
+
+extern "C" {
+
+int sfm_knn2_dev(sfm_ctx* ctx, int norm, const void* d_q, int nq, size_t q_stride, const void* d_t,
+                 int nt, size_t t_stride, int d, int32_t* d_idx, float* d_dist) {
+    SFM_RETURN_IF(check_common(ctx, norm, nq, nt, d));
+    if (nq == 0) return SFM_OK;
+    if (!d_q || !d_idx || !d_dist || (nt > 0 && !d_t))
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (norm != SFM_NORM_HAMMING)
+        return l2_knn2_dev(ctx, norm == SFM_NORM_L2SQR, static_cast<const float*>(d_q), nq,
+                           q_stride, static_cast<const float*>(d_t), nt, t_stride, d, d_idx,
+                           d_dist);
+    if (q_stride < (size_t)d || (nt > 0 && t_stride < (size_t)d))
+        return set_error(ctx, SFM_E_INVALID, "row stride smaller than the row");
+
+    KnnPlan plan = make_knn_plan(ctx, norm, d, nq, nt, 1);
+    const size_t row_bytes = (size_t)plan.row_words * 4;
+    const bool q_ok = is_packed(d_q, q_stride, d, plan.row_words);
+    const bool t_ok = nt == 0 || is_packed(d_t, t_stride, d, plan.row_words);
+    Carver sz(nullptr);
+    if (!q_ok) sz.take<uint8_t>((size_t)nq * row_bytes);
+    if (!t_ok) sz.take<uint8_t>((size_t)nt * row_bytes);
+    sz.take<uint32_t>((size_t)plan.splits * plan.rows_max * 2);
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
+    Carver c(ws);
+    const void* qp = d_q;
+    const void* tp = d_t;
+    if (!q_ok) {
+        void* p = c.take<uint8_t>((size_t)nq * row_bytes);
+        SFM_RETURN_IF(pack_rows(ctx, d_q, nq, q_stride, d, p, plan.row_words));
+        qp = p;
+    }
+    if (!t_ok) {
+        void* p = c.take<uint8_t>((size_t)nt * row_bytes);
+        SFM_RETURN_IF(pack_rows(ctx, d_t, nt, t_stride, d, p, plan.row_words));
+        tp = p;
+    }
+    uint32_t* keys = c.take<uint32_t>((size_t)plan.splits * plan.rows_max * 2);
+    KnnBatch b{};
+    b.q_base = qp;
+    b.t_base = tp;
+    b.nq_uniform = nq;
+    b.nt_uniform = nt;
+    b.n_problems = 1;
+    SFM_RETURN_IF(launch_hamming_knn2(ctx, plan, b, keys));
+    return launch_knn_finalize(ctx, plan, keys, nq, nt, d_idx, d_dist);
+}
+
+int sfm_knn2(sfm_ctx* ctx, int norm, const void* q, int nq, size_t q_stride, const void* t, int nt,
+             size_t t_stride, int d, int32_t* idx, float* dist) {
+    SFM_RETURN_IF(check_common(ctx, norm, nq, nt, d));
+    if (nq == 0) return SFM_OK;
+    if (!q || !idx || !dist || (nt > 0 && !t))
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t elem = norm == SFM_NORM_HAMMING ? 1 : sizeof(float);
+    const size_t row = (size_t)d * elem;
+    if (q_stride < row || (nt > 0 && t_stride < row))
+        return set_error(ctx, SFM_E_INVALID, "row stride smaller than the row");
+    // rows are staged densely (stride == row bytes)
+    Carver sz(nullptr);
+    sz.take<uint8_t>((size_t)nq * row);
+    sz.take<uint8_t>((size_t)nt * row);
+    sz.take<int32_t>((size_t)nq * 2);
+    sz.take<float>((size_t)nq * 2);
+    void* st;
+    SFM_RETURN_IF(staging(ctx, sz.total(), &st));
+    Carver c(st);
+    uint8_t* dq = c.take<uint8_t>((size_t)nq * row);
+    uint8_t* dt = c.take<uint8_t>((size_t)nt * row);
+    int32_t* di = c.take<int32_t>((size_t)nq * 2);
+    float* dd = c.take<float>((size_t)nq * 2);
+    SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(dq, row, q, q_stride, row, nq, hipMemcpyHostToDevice,
+                                        ctx->stream));
+    if (nt > 0)
+        SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(dt, row, t, t_stride, row, nt, hipMemcpyHostToDevice,
+                                            ctx->stream));
+    SFM_RETURN_IF(sfm_knn2_dev(ctx, norm, dq, nq, row, dt, nt, row, d, di, dd));
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(idx, di, sizeof(int32_t) * 2 * nq, hipMemcpyDeviceToHost,
+                                      ctx->stream));
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(dist, dd, sizeof(float) * 2 * nq, hipMemcpyDeviceToHost,
+                                      ctx->stream));
+    SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SFM_OK;
+}
+
+int sfm_ratio_matches(sfm_ctx* ctx, int norm, const void* q, int nq, size_t q_stride, const void* t,
+                      int nt, size_t t_stride, int d, float ratio, sfm_dmatch* out,
+                      int* out_count) {
+    SFM_RETURN_IF(check_common(ctx, norm, nq, nt, d));
+    if (!out_count) return set_error(ctx, SFM_E_INVALID, "out_count is NULL");
+    *out_count = 0;
+    if (nq == 0 || nt < 2) return SFM_OK;
+    if (!q || !t || !out) return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t elem = norm == SFM_NORM_HAMMING ? 1 : sizeof(float);
+    const size_t row = (size_t)d * elem;
+    if (q_stride < row || t_stride < row)
+        return set_error(ctx, SFM_E_INVALID, "row stride smaller than the row");
+    Carver sz(nullptr);
+    sz.take<uint8_t>((size_t)nq * row);
+    sz.take<uint8_t>((size_t)nt * row);
+    sz.take<int32_t>((size_t)nq * 2);
+    sz.take<float>((size_t)nq * 2);
+    sz.take<sfm_dmatch>((size_t)nq);
+    sz.take<int32_t>(4);
+    void* st;
+    SFM_RETURN_IF(staging(ctx, sz.total(), &st));
+    Carver c(st);
+    uint8_t* dq = c.take<uint8_t>((size_t)nq * row);
+    uint8_t* dt = c.take<uint8_t>((size_t)nt * row);
+    int32_t* di = c.take<int32_t>((size_t)nq * 2);
+    float* dd = c.take<float>((size_t)nq * 2);
+    sfm_dmatch* dm = c.take<sfm_dmatch>((size_t)nq);
+    int32_t* dc = c.take<int32_t>(4);
+    SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(dq, row, q, q_stride, row, nq, hipMemcpyHostToDevice,
+                                        ctx->stream));
+    SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(dt, row, t, t_stride, row, nt, hipMemcpyHostToDevice,
+                                        ctx->stream));
+    SFM_RETURN_IF(sfm_knn2_dev(ctx, norm, dq, nq, row, dt, nt, row, d, di, dd));
+    SFM_RETURN_IF(launch_ratio_compact(ctx, di, dd, nq, nt, ratio, dm, dc));
+    int32_t count = 0;
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(&count, dc, sizeof(int32_t), hipMemcpyDeviceToHost,
+                                      ctx->stream));
+    SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (count > 0)
+        SFM_HIP_CHECK(ctx, hipMemcpy(out, dm, sizeof(sfm_dmatch) * (size_t)count,
+                                     hipMemcpyDeviceToHost));
+    *out_count = count;
+    return SFM_OK;
+}
+
+size_t sfm_match_pairs_workspace(int norm, int rows_per_frame, int d, int n_pairs) {
+    if (rows_per_frame <= 0 || d <= 0 || n_pairs <= 0) return 0;
+    const int chunk = std::min(n_pairs, kPairChunk);
+    if (norm != SFM_NORM_HAMMING) return l2_match_pairs_workspace(rows_per_frame, d, chunk);
+    sfm_ctx fake;
+    KnnPlan plan = make_knn_plan(&fake, norm, d, rows_per_frame, rows_per_frame, 2 * chunk);
+    return hamming_pairs_bytes(plan, chunk);
+}
+
+int sfm_match_pairs_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames,
+                        size_t frame_stride, int rows_per_frame, const int32_t* d_counts, int d,
+                        const int32_t* d_pairs, int n_pairs, float ratio, sfm_dmatch* d_matches,
+                        int cap, int32_t* d_match_counts) {
+    SFM_RETURN_IF(check_common(ctx, norm, rows_per_frame, rows_per_frame, d));
+    if (n_pairs < 0 || n_frames < 0 || cap < 0)
+        return set_error(ctx, SFM_E_INVALID, "negative count");
+    if (n_pairs == 0) return SFM_OK;
+    if (!d_desc || !d_pairs || !d_matches || !d_match_counts)
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (norm != SFM_NORM_HAMMING) {
+        for (int p0 = 0; p0 < n_pairs; p0 += kPairChunk) {
+            const int np = std::min(kPairChunk, n_pairs - p0);
+            SFM_RETURN_IF(l2_match_pairs_dev(ctx, norm == SFM_NORM_L2SQR,
+                                             static_cast<const float*>(d_desc), frame_stride,
+                                             rows_per_frame, d_counts, d, d_pairs + 2 * (size_t)p0,
+                                             np, ratio, d_matches + (size_t)p0 * cap, cap,
+                                             d_match_counts + p0));
+        }
+        return SFM_OK;
+    }
+    if (frame_stride < (size_t)rows_per_frame * d)
+        return set_error(ctx, SFM_E_INVALID, "frame stride smaller than a frame");
+
+    const int chunk = std::min(n_pairs, kPairChunk);
+    KnnPlan plan = make_knn_plan(ctx, norm, d, rows_per_frame, rows_per_frame, 2 * chunk);
+    const size_t row_bytes = (size_t)plan.row_words * 4;
+    const bool packed = d == plan.row_words * 4 && (frame_stride & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(d_desc) & 15) == 0;
+    Carver sz(nullptr);
+    if (!packed) sz.take<uint8_t>((size_t)n_frames * rows_per_frame * row_bytes);
+    const size_t fixed = sz.total();
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, fixed + hamming_pairs_bytes(plan, chunk), &ws));
+    Carver c(ws);
+    const void* base = d_desc;
+    size_t fstride = frame_stride;
+    if (!packed) {
+        uint8_t* p = c.take<uint8_t>((size_t)n_frames * rows_per_frame * row_bytes);
+        fstride = (size_t)rows_per_frame * row_bytes;
+        for (int f = 0; f < n_frames; ++f)
+            SFM_RETURN_IF(pack_rows(ctx, static_cast<const uint8_t*>(d_desc) + f * frame_stride,
+                                    rows_per_frame, (size_t)d, d, p + f * fstride, plan.row_words));
+        base = p;
+    }
+    const size_t carve_mark = c.off;
+    for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
+        const int np = std::min(chunk, n_pairs - p0);
+        c.off = carve_mark;
+        SFM_RETURN_IF(hamming_pairs_packed(ctx, plan, base, fstride, rows_per_frame, d_counts,
+                                           d_pairs + 2 * (size_t)p0, np, ratio,
+                                           d_matches + (size_t)p0 * cap, cap, d_match_counts + p0,
+                                           c));
+    }
+    return SFM_OK;
+}
+
+int sfm_robust_matches(sfm_ctx* ctx, int norm, const void* prev, int n_prev, size_t prev_stride,
+                       const void* curr, int n_curr, size_t curr_stride, int d, float ratio,
+                       sfm_dmatch* out, int* out_count) {
+    SFM_RETURN_IF(check_common(ctx, norm, n_prev, n_curr, d));
+    if (!out_count) return set_error(ctx, SFM_E_INVALID, "out_count is NULL");
+    *out_count = 0;
+    if (n_prev < 2 || n_curr < 2) return SFM_OK;  // no ratio test can pass in both directions
+    if (!prev || !curr || !out) return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t elem = norm == SFM_NORM_HAMMING ? 1 : sizeof(float);
+    const size_t row = (size_t)d * elem;
+    if (prev_stride < row || curr_stride < row)
+        return set_error(ctx, SFM_E_INVALID, "row stride smaller than the row");
+    const int rows = std::max(n_prev, n_curr);
+    const int cap = std::min(n_prev, n_curr);
+    // two-frame stack in the staging buffer: frame 0 = prev, frame 1 = curr
+    const size_t fstride = align_up((size_t)rows * row, 256);
+    Carver sz(nullptr);
+    sz.take<uint8_t>(2 * fstride);
+    sz.take<int32_t>(8);
+    sz.take<sfm_dmatch>((size_t)cap);
+    void* st;
+    SFM_RETURN_IF(staging(ctx, sz.total(), &st));
+    Carver c(st);
+    uint8_t* stack = c.take<uint8_t>(2 * fstride);
+    int32_t* meta = c.take<int32_t>(8);  // pairs[2], counts[2], match count
+    sfm_dmatch* dm = c.take<sfm_dmatch>((size_t)cap);
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(stack, 0, 2 * fstride, ctx->stream));
+    SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(stack, row, prev, prev_stride, row, n_prev,
+                                        hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(stack + fstride, row, curr, curr_stride, row, n_curr,
+                                        hipMemcpyHostToDevice, ctx->stream));
+    const int32_t h_meta[8] = {0, 1, n_prev, n_curr, 0, 0, 0, 0};
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(meta, h_meta, sizeof(h_meta), hipMemcpyHostToDevice,
+                                      ctx->stream));
+    SFM_RETURN_IF(sfm_match_pairs_dev(ctx, norm, stack, 2, fstride, rows, meta + 2, d, meta, 1,
+                                      ratio, dm, cap, meta + 4));
+    int32_t count = 0;
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(&count, meta + 4, sizeof(int32_t), hipMemcpyDeviceToHost,
+                                      ctx->stream));
+    SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (count > cap) count = cap;
+    if (count > 0)
+        SFM_HIP_CHECK(ctx, hipMemcpy(out, dm, sizeof(sfm_dmatch) * (size_t)count,
+                                     hipMemcpyDeviceToHost));
+    *out_count = count;
+    return SFM_OK;
+}
+
+}  // extern "C"

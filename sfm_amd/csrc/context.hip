@@ -1,0 +1,129 @@
+// Context, error reporting and device buffers of libsfm_hip.so.
+#include "sfm_internal.h"
+
+#include <new>
+
+namespace {
+thread_local std::string g_create_error;
+}
+
+namespace sfm {
+
+int set_error(sfm_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+static int grow(sfm_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
+    if (bytes <= *cap) return SFM_OK;
+    // The old buffer may still be in use by work queued on the stream.
+    SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (*buf) {
+        SFM_HIP_CHECK(ctx, hipFree(*buf));
+        *buf = nullptr;
+        *cap = 0;
+    }
+    size_t want = align_up(bytes + bytes / 8, size_t(1) << 20);
+    hipError_t e = hipMalloc(buf, want);
+    if (e != hipSuccess) {
+        *buf = nullptr;
+        return set_error(ctx, SFM_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    *cap = want;
+    return SFM_OK;
+}
+
+int workspace(sfm_ctx* ctx, size_t bytes, void** out) {
+    SFM_RETURN_IF(grow(ctx, &ctx->ws, &ctx->ws_bytes, bytes));
+    *out = ctx->ws;
+    return SFM_OK;
+}
+
+int staging(sfm_ctx* ctx, size_t bytes, void** out) {
+    SFM_RETURN_IF(grow(ctx, &ctx->staging, &ctx->staging_bytes, bytes));
+    *out = ctx->staging;
+    return SFM_OK;
+}
+
+}  // namespace sfm
+
+static int create_common(int device, hipStream_t stream, bool own, sfm_ctx** out) {
+    if (!out) return sfm::set_error(nullptr, SFM_E_INVALID, "sfm_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return sfm::set_error(nullptr, SFM_E_HIP, "no HIP device available: %s",
+                              e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count)
+        return sfm::set_error(nullptr, SFM_E_INVALID, "device %d out of range [0,%d)", device, count);
+    e = hipSetDevice(device);
+    if (e != hipSuccess)
+        return sfm::set_error(nullptr, SFM_E_HIP, "hipSetDevice(%d) failed: %s", device,
+                              hipGetErrorString(e));
+    sfm_ctx* ctx = new (std::nothrow) sfm_ctx();
+    if (!ctx) return sfm::set_error(nullptr, SFM_E_NOMEM, "out of host memory");
+    ctx->device = device;
+    if (own) {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return sfm::set_error(nullptr, SFM_E_HIP, "hipStreamCreate failed: %s",
+                                  hipGetErrorString(e));
+        }
+        ctx->own_stream = true;
+    } else {
+        ctx->stream = stream;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->num_cus = prop.multiProcessorCount;
+    *out = ctx;
+    return SFM_OK;
+}
+
+extern "C" {
+
+int sfm_ctx_create(int device, sfm_ctx** out) { return create_common(device, nullptr, true, out); }
+
+int sfm_ctx_create_on_stream(int device, void* hip_stream, sfm_ctx** out) {
+    return create_common(device, static_cast<hipStream_t>(hip_stream), false, out);
+}
+
+void sfm_ctx_destroy(sfm_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->staging) (void)hipFree(ctx->staging);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int sfm_ctx_synchronize(sfm_ctx* ctx) {
+    if (!ctx) return sfm::set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SFM_OK;
+}
+
+int sfm_ctx_reserve(sfm_ctx* ctx, size_t bytes) {
+    if (!ctx) return sfm::set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    void* p;
+    return sfm::workspace(ctx, bytes, &p);
+}
+
+const char* sfm_last_error(const sfm_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+const char* sfm_version(void) { return "sfm_hip 0.1 gfx950"; }
+
+}  // extern "C"

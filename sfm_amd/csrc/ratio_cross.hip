@@ -1,0 +1,194 @@
+// Ratio test, cross-check and ordered compaction of the 2-NN results.
+//
+// Replaces the host loops of DescriptorMatcher::ratioMaches (Source Files/
+// feature_processing.cpp:126-129) and the cross-check of findRobustMatches
+// (:159-176).  One 1024-lane workgroup handles one frame pair: it merges the
+// per-split keys of both directions, applies  d0 < ratio * d1  in float exactly
+// as the reference does, then walks the backward list in ascending curr index
+// (the reference's output order) and keeps the pairs whose forward match points
+// back, compacting them with a ballot / prefix-popcount scan.
+#include "sfm_internal.h"
+
+namespace sfm {
+
+namespace {
+
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+constexpr int kIdxBits = 18;
+constexpr int kThreads = 1024;
+
+struct CrossArgs {
+    const uint2* keys;
+    int splits;
+    int rows_max;
+    const int32_t* counts;
+    int n_prev_uniform;
+    int n_curr_uniform;
+    const int32_t* pairs;
+    float ratio;
+    int32_t* best;      // [2*n_pairs][rows_max]: ratio-passing neighbour or -1
+    float* best_dist;   // [2*n_pairs][rows_max]
+    sfm_dmatch* matches;
+    int cap;
+    int32_t* match_counts;
+};
+
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__global__ __launch_bounds__(kThreads) void ratio_cross_kernel(CrossArgs a) {
+    __shared__ int wave_count[kThreads / 64];
+    const int pair = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int fa = a.pairs[2 * pair], fb = a.pairs[2 * pair + 1];
+    const int n_prev = a.counts ? a.counts[fa] : a.n_prev_uniform;
+    const int n_curr = a.counts ? a.counts[fb] : a.n_curr_uniform;
+    const uint32_t mask = (1u << kIdxBits) - 1;
+
+    for (int dir = 0; dir < 2; ++dir) {
+        const int nq = dir ? n_curr : n_prev;
+        const int nt = dir ? n_prev : n_curr;
+        const size_t problem = 2 * (size_t)pair + dir;
+        const uint2* keys = a.keys + problem * a.splits * (size_t)a.rows_max;
+        for (int q = tid; q < nq; q += kThreads) {
+            uint32_t m1 = kNoKey, m2 = kNoKey;
+            for (int s = 0; s < a.splits; ++s) {
+                const uint2 k = keys[(size_t)s * a.rows_max + q];
+                m2 = med3_u32(m1, m2, k.x);
+                m1 = min(m1, k.x);
+                m2 = med3_u32(m1, m2, k.y);
+                m1 = min(m1, k.y);
+            }
+            const float d0 = (float)(m1 >> kIdxBits), d1 = (float)(m2 >> kIdxBits);
+            // feature_processing.cpp:127, float * float, strict <
+            const bool pass = nt >= 2 && d0 < a.ratio * d1;
+            a.best[problem * a.rows_max + q] = pass ? (int32_t)(m1 & mask) : -1;
+            a.best_dist[problem * a.rows_max + q] = d0;
+        }
+    }
+    __syncthreads();  // the block's own global writes are visible to it afterwards
+
+    const int32_t* fwd = a.best + (2 * (size_t)pair) * a.rows_max;
+    const int32_t* bwd = fwd + a.rows_max;
+    const float* fwd_dist = a.best_dist + (2 * (size_t)pair) * a.rows_max;
+    const int lane = tid & 63, wave = tid >> 6;
+    int running = 0;
+    for (int c0 = 0; c0 < n_curr; c0 += kThreads) {
+        const int c = c0 + tid;
+        int p = -1;
+        bool ok = false;
+        if (c < n_curr) {
+            p = bwd[c];
+            ok = p >= 0 && p < n_prev && fwd[p] == c;
+        }
+        const unsigned long long ballot = __ballot(ok);
+        const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_count[wave] = __popcll(ballot);
+        __syncthreads();
+        int offset = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) {
+            const int cnt = wave_count[w];
+            offset += w < wave ? cnt : 0;
+            total += cnt;
+        }
+        if (ok) {
+            const int pos = running + offset + prefix;
+            if (pos < a.cap) {
+                sfm_dmatch m;
+                m.queryIdx = p;
+                m.trainIdx = c;
+                m.imgIdx = 0;
+                m.distance = fwd_dist[p];
+                a.matches[(size_t)pair * a.cap + pos] = m;
+            }
+        }
+        running += total;
+        __syncthreads();
+    }
+    if (tid == 0) a.match_counts[pair] = running;
+}
+
+// Single-direction ratio filter with ordered compaction (ratioMaches alone).
+__global__ __launch_bounds__(kThreads) void ratio_compact_kernel(const int32_t* __restrict__ idx,
+                                                                 const float* __restrict__ dist,
+                                                                 int nq, int nt, float ratio,
+                                                                 sfm_dmatch* __restrict__ out,
+                                                                 int32_t* __restrict__ out_count) {
+    __shared__ int wave_count[kThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int running = 0;
+    for (int q0 = 0; q0 < nq; q0 += kThreads) {
+        const int q = q0 + tid;
+        bool ok = false;
+        float d0 = 0.f;
+        int t0 = -1;
+        if (q < nq && nt >= 2) {
+            d0 = dist[2 * q];
+            t0 = idx[2 * q];
+            ok = d0 < ratio * dist[2 * q + 1];
+        }
+        const unsigned long long ballot = __ballot(ok);
+        const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_count[wave] = __popcll(ballot);
+        __syncthreads();
+        int offset = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) {
+            const int cnt = wave_count[w];
+            offset += w < wave ? cnt : 0;
+            total += cnt;
+        }
+        if (ok) {
+            sfm_dmatch m;
+            m.queryIdx = q;
+            m.trainIdx = t0;
+            m.imgIdx = 0;
+            m.distance = d0;
+            out[running + offset + prefix] = m;
+        }
+        running += total;
+        __syncthreads();
+    }
+    if (tid == 0) *out_count = running;
+}
+
+}  // namespace
+
+int launch_ratio_cross(sfm_ctx* ctx, const KnnPlan& plan, const uint32_t* d_keys,
+                       const int32_t* d_counts, int rows_uniform_prev, int rows_uniform_curr,
+                       const int32_t* d_pairs, int n_pairs, float ratio, int32_t* d_best,
+                       float* d_best_dist, sfm_dmatch* d_matches, int cap,
+                       int32_t* d_match_counts) {
+    if (n_pairs <= 0) return SFM_OK;
+    CrossArgs a{};
+    a.keys = reinterpret_cast<const uint2*>(d_keys);
+    a.splits = plan.splits;
+    a.rows_max = plan.rows_max;
+    a.counts = d_counts;
+    a.n_prev_uniform = rows_uniform_prev;
+    a.n_curr_uniform = rows_uniform_curr;
+    a.pairs = d_pairs;
+    a.ratio = ratio;
+    a.best = d_best;
+    a.best_dist = d_best_dist;
+    a.matches = d_matches;
+    a.cap = cap;
+    a.match_counts = d_match_counts;
+    hipLaunchKernelGGL(ratio_cross_kernel, dim3(n_pairs), dim3(kThreads), 0, ctx->stream, a);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+int launch_ratio_compact(sfm_ctx* ctx, const int32_t* d_idx, const float* d_dist, int nq, int nt,
+                         float ratio, sfm_dmatch* d_out, int32_t* d_count) {
+    hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, d_idx,
+                       d_dist, nq, nt, ratio, d_out, d_count);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+}  // namespace sfm

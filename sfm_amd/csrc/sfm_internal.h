@@ -1,0 +1,113 @@
+// Internal declarations shared by the HIP translation units of libsfm_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "sfm_hip.h"
+
+struct sfm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void* ws = nullptr;       // grow-only device workspace
+    size_t ws_bytes = 0;
+    void* staging = nullptr;  // grow-only device buffer for the host-pointer entry points
+    size_t staging_bytes = 0;
+    int num_cus = 256;
+    std::string err;
+};
+
+namespace sfm {
+
+int set_error(sfm_ctx* ctx, int code, const char* fmt, ...);
+
+#define SFM_HIP_CHECK(ctx, expr)                                                        \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess)                                                           \
+            return sfm::set_error((ctx), SFM_E_HIP, "%s failed: %s (%s:%d)", #expr,     \
+                                  hipGetErrorString(_e), __FILE__, __LINE__);           \
+    } while (0)
+
+#define SFM_RETURN_IF(expr)        \
+    do {                           \
+        int _rc = (expr);          \
+        if (_rc != SFM_OK) return _rc; \
+    } while (0)
+
+// Device workspace of at least `bytes`; contents are not preserved on growth.
+int workspace(sfm_ctx* ctx, size_t bytes, void** out);
+// Second buffer used by host-pointer wrappers to stage inputs/outputs.
+int staging(sfm_ctx* ctx, size_t bytes, void** out);
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Carves aligned sub-buffers out of one allocation.
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base(static_cast<char*>(b)) {}
+    template <typename T>
+    T* take(size_t count) {
+        off = align_up(off, 256);
+        T* p = reinterpret_cast<T*>(base ? base + off : nullptr);
+        off += count * sizeof(T);
+        return p;
+    }
+    size_t total() const { return align_up(off, 256); }
+};
+
+// ---- matching (hamming_knn2.hip, l2_knn2_mfma.hip, ratio_cross.hip) --------
+
+// Geometry of one batched 2-NN launch.  A "problem" is one (query frame, train
+// frame) direction; a pair contributes two problems.
+struct KnnPlan {
+    int norm;
+    int d;            // bytes (Hamming) or floats (L2) per row
+    int row_words;    // padded 32-bit words per packed row
+    int q_per_block;  // query rows one workgroup owns
+    int splits;       // train-dimension splits per problem
+    int rows_max;     // query-row capacity: stride of the per-split key arrays
+};
+
+// nq_max / nt_max: largest query / train row count of any problem in the launch.
+KnnPlan make_knn_plan(const sfm_ctx* ctx, int norm, int d, int nq_max, int nt_max, int n_problems);
+
+// Zero-padded repack of `n` rows of `d_bytes` bytes (stride src_stride) into rows
+// of row_words*4 bytes.
+int pack_rows(sfm_ctx* ctx, const void* d_src, int n, size_t src_stride, int d_bytes,
+              void* d_dst, int row_words);
+
+struct KnnBatch {
+    const void* q_base;       // packed rows, frame f at q_base + f*frame_stride
+    const void* t_base;
+    size_t q_frame_stride;    // bytes
+    size_t t_frame_stride;
+    const int32_t* d_counts_q;  // per-frame row counts or nullptr
+    const int32_t* d_counts_t;
+    int nq_uniform, nt_uniform;
+    const int32_t* d_pairs;   // [n_pairs][2] or nullptr (single problem q->t)
+    int n_problems;           // 2*n_pairs when d_pairs, else 1
+};
+
+// Writes partial top-2 keys: keys[problem][split][row][2] (uint32 for Hamming,
+// uint64 for L2 candidates, see the kernels).
+int launch_hamming_knn2(sfm_ctx* ctx, const KnnPlan& plan, const KnnBatch& b, uint32_t* d_keys);
+
+// Merges the splits of a single problem and writes idx/dist [nq][2].
+int launch_knn_finalize(sfm_ctx* ctx, const KnnPlan& plan, const uint32_t* d_keys, int nq,
+                        int nt, int32_t* d_idx, float* d_dist);
+
+// Per pair: merge, ratio test both ways, cross-check, ordered compaction.
+int launch_ratio_cross(sfm_ctx* ctx, const KnnPlan& plan, const uint32_t* d_keys,
+                       const int32_t* d_counts, int rows_uniform_prev, int rows_uniform_curr,
+                       const int32_t* d_pairs, int n_pairs, float ratio, int32_t* d_best,
+                       float* d_best_dist, sfm_dmatch* d_matches, int cap,
+                       int32_t* d_match_counts);
+
+}  // namespace sfm
