@@ -1,0 +1,160 @@
+"""GPU parity tests of pyramidal Lucas-Kanade: HIP kernels through the C ABI
+against the golden vectors and the CPU oracle.
+
+The GPU accumulates the normal-equation sums exactly in integers, so against the
+oracle's exact-accumulator mode the result is required to be bit-identical.
+Against the oracle's float-accumulator mode (OpenCV's own accumulator type, in
+one of its possible summation orders) positions must agree within 1e-3 px.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL_PX = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from sfm_amd import capi
+
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def test_pyrlk_golden_exact(ctx):
+    g = load_golden("lk.npz")
+    nxt, st, err = ctx.pyrlk(g["lk_prev"], g["lk_curr"], g["lk_pts"], win=(9, 9), max_level=3,
+                             crit_type=3, max_count=30, epsilon=0.01)
+    np.testing.assert_array_equal(st, g["lk_status_1"])
+    np.testing.assert_array_equal(nxt, g["lk_next_1"])
+    np.testing.assert_array_equal(err, g["lk_err_1"])
+    # float-accumulator golden: same status, positions within tolerance
+    ok = st.astype(bool) & g["lk_status_0"].astype(bool)
+    assert np.abs(nxt[ok] - g["lk_next_0"][ok]).max() < TOL_PX
+
+
+def test_pyrlk_golden_second_config(ctx):
+    g = load_golden("lk.npz")
+    nxt, st, err = ctx.pyrlk(g["lk_prev"], g["lk_curr"], g["lk_pts"], win=(7, 5), max_level=1,
+                             crit_type=3, max_count=10, epsilon=0.0)
+    np.testing.assert_array_equal(st, g["lk2_status"])
+    np.testing.assert_array_equal(nxt, g["lk2_next"])
+    np.testing.assert_array_equal(err, g["lk2_err"])
+
+
+def _pair(h, w, seed, n, margin=4):
+    from sfm_amd import synth
+
+    prev, curr = synth.lk_pair(h, w, seed=seed, shift=(1.7, -1.1), angle_deg=0.3)
+    pts = synth.grid_points(h, w, n, seed=seed, margin=margin)
+    return prev, curr, pts
+
+
+@pytest.mark.parametrize("win,max_level,crit", [
+    ((21, 21), 3, (3, 30, 0.01)),
+    ((9, 9), 2, (3, 30, 0.01)),
+    ((15, 15), 4, (3, 20, 0.03)),
+    ((30, 30), 5, (3, 100, 0.0)),   # the reference application's defaults, clamped count
+    ((41, 41), 2, (1, 15, 0.0)),
+    ((13, 7), 3, (2, 0, 0.02)),
+    ((3, 3), 1, (3, 5, 0.01)),
+])
+def test_pyrlk_vs_oracle(ctx, oracle, win, max_level, crit):
+    h, w, n = 240, 320, 1500
+    prev, curr, pts = _pair(h, w, 42 + win[0], n)
+    # some points outside / on the border
+    pts[:5] = [[-40.0, 10.0], [w + 50.0, 5.0], [0.0, 0.0], [w - 1.0, h - 1.0], [10.0, h + 45.0]]
+    kw = dict(win=win, max_level=max_level, crit_type=crit[0], max_count=crit[1], epsilon=crit[2])
+    nxt, st, err = ctx.pyrlk(prev, curr, pts, **kw)
+    onxt, ost, oerr = oracle.pyrlk(prev, curr, pts, acc_exact=True, **kw)
+    np.testing.assert_array_equal(st, ost)
+    np.testing.assert_array_equal(nxt, onxt)
+    np.testing.assert_array_equal(err, oerr)
+    assert st.sum() > 0.5 * n or win[0] <= 3
+    fnxt, fst, ferr = oracle.pyrlk(prev, curr, pts, acc_exact=False, **kw)
+    both = st.astype(bool) & fst.astype(bool)
+    # a point whose status differs between accumulator types sits on a threshold
+    assert (st != fst).mean() < 0.01
+    diff = np.abs(nxt[both] - fnxt[both]).max(axis=1)
+    # points that stop on different iterations under the two accumulators differ by up to the
+    # termination epsilon; they are rare, everything else agrees within the tolerance
+    assert (diff < TOL_PX).mean() > 0.995
+    assert np.median(diff) < 1e-5
+
+
+def test_pyrlk_c2_shape_and_truth(ctx, oracle):
+    """The benchmark configuration: 1280x720, 5000 points, 21x21, maxLevel 3."""
+    from sfm_amd import synth
+
+    prev, curr = synth.lk_pair(720, 1280, seed=42)
+    pts = synth.grid_points(720, 1280, 5000, seed=42, margin=15)
+    nxt, st, err = ctx.pyrlk(prev, curr, pts)
+    onxt, ost, oerr = oracle.pyrlk(prev, curr, pts, acc_exact=True)
+    np.testing.assert_array_equal(st, ost)
+    np.testing.assert_array_equal(nxt, onxt)
+    np.testing.assert_array_equal(err, oerr)
+    truth = synth.warp_points(pts.astype(np.float64), (720, 1280))
+    ok = st.astype(bool)
+    assert ok.mean() > 0.95
+    assert np.median(np.abs(nxt[ok] - truth[ok])) < 0.05
+
+
+def test_pyrlk_identical_images(ctx, oracle):
+    prev, _, pts = _pair(200, 260, 3, 400)
+    nxt, st, err = ctx.pyrlk(prev, prev, pts)
+    assert st.all()
+    # zero flow; (x*2^-l - halfWin + halfWin)*2^l rounds by a few float ulps of the coordinate
+    np.testing.assert_allclose(nxt, pts, rtol=0, atol=5e-4)
+    assert err.max() < 0.01 and (err == 0).mean() > 0.9
+    onxt, _, oerr = oracle.pyrlk(prev, prev, pts, acc_exact=True)
+    np.testing.assert_array_equal(nxt, onxt)
+    np.testing.assert_array_equal(err, oerr)
+
+
+def test_pyrlk_empty_and_bad_arguments(ctx):
+    from sfm_amd import capi
+
+    img = np.zeros((40, 50), np.uint8)
+    nxt, st, err = ctx.pyrlk(img, img, np.zeros((0, 2), np.float32))
+    assert nxt.shape == (0, 2)
+    with pytest.raises(capi.SfmError):
+        ctx.pyrlk(img, img, np.zeros((3, 2), np.float32), win=(2, 2))
+    with pytest.raises(capi.SfmError):
+        ctx.pyrlk(img, img, np.zeros((3, 2), np.float32), win=(45, 45))
+    # flat image: every point fails the minimum-eigenvalue test
+    nxt, st, err = ctx.pyrlk(img, img, np.full((7, 2), 20.0, np.float32), win=(9, 9))
+    assert (st == 0).all()
+
+
+def test_pyrlk_batch_dev(ctx, oracle):
+    import torch
+
+    from sfm_amd import capi
+
+    h, w, n, B = 120, 160, 300, 5
+    prevs, currs, ptss = [], [], []
+    for b in range(B):
+        p, c, pts = _pair(h, w, 100 + b, n)
+        prevs.append(p)
+        currs.append(c)
+        ptss.append(pts)
+    dev = torch.device("cuda:0")
+    d_prev = torch.from_numpy(np.stack(prevs)).to(dev)
+    d_curr = torch.from_numpy(np.stack(currs)).to(dev)
+    d_pts = torch.from_numpy(np.stack(ptss)).to(dev)
+    d_out = torch.zeros((B, n, 2), dtype=torch.float32, device=dev)
+    d_st = torch.zeros((B, n), dtype=torch.uint8, device=dev)
+    d_err = torch.zeros((B, n), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx.pyrlk_batch_dev(d_prev, d_curr, B, h * w, w, h, w, d_pts, n, (21, 21), 3, 3, 30, 0.01, 1e-4,
+                        10.0, d_out, d_st, d_err)
+    ctx.synchronize()
+    for b in range(B):
+        onxt, ost, oerr = oracle.pyrlk(prevs[b], currs[b], ptss[b], acc_exact=True)
+        np.testing.assert_array_equal(d_st[b].cpu().numpy(), ost)
+        np.testing.assert_array_equal(d_out[b].cpu().numpy(), onxt)
+        np.testing.assert_array_equal(d_err[b].cpu().numpy(), oerr)

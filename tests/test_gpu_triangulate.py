@@ -1,0 +1,128 @@
+"""GPU parity tests of DLT triangulation + reprojection filter (fp64).
+
+Tolerance: 3-D points within 1e-4 relative of the oracle (BASELINE.json's bound;
+the observed agreement is ~1e-12 because both run the same one-sided Jacobi in
+fp64), reprojection error within 1e-6 relative; the mask is compared wherever
+no threshold lies within a small band of the value.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL_REL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from sfm_amd import capi
+
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _well(sv):
+    return sv[:, 3] / sv[:, 2] < 0.5
+
+
+def test_triangulate_golden(ctx):
+    g = load_golden("triangulate.npz")
+    X, rgb, mask, err = ctx.triangulate(g["K"], g["prev_pose"], g["curr_pose"], g["R"], g["t"],
+                                        g["p1"], g["p2"])
+    well = _well(g["sv"])
+    rel = np.linalg.norm(X - g["X"], axis=1) / np.linalg.norm(g["X"], axis=1)
+    assert rel[well].max() < 1e-8 < TOL_REL
+    np.testing.assert_allclose(err[well], g["err"][well], rtol=1e-6, atol=1e-7)
+    band = (np.abs(g["err"] - 3.0) < 1e-6) | (np.abs(g["depth"] - 250.0) < 1e-6)
+    np.testing.assert_array_equal(mask[well & ~band], g["mask"][well & ~band])
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 1000, 100003])
+def test_triangulate_vs_oracle(ctx, oracle, n):
+    from sfm_amd import synth
+
+    s = synth.triangulation_set(n, seed=7 + n)
+    rng = np.random.default_rng(n)
+    img = rng.integers(0, 256, size=(720, 1280, 3), dtype=np.uint8)
+    args = (s["K"], s["prev_pose"], s["curr_pose"], s["R"], s["t"], s["p1"], s["p2"])
+    X, rgb, mask, err = ctx.triangulate(*args, bgr=img)
+    oX, orgb, omask, oerr = oracle.triangulate(*args, bgr=img)
+    rel = np.linalg.norm(X - oX, axis=1) / np.maximum(np.linalg.norm(oX, axis=1), 1e-300)
+    assert rel.max() < 1e-9 < TOL_REL
+    np.testing.assert_allclose(err, oerr, rtol=1e-6, atol=1e-9)
+    np.testing.assert_array_equal(rgb, orgb)
+    band = np.abs(oerr - 3.0) < 1e-6
+    np.testing.assert_array_equal(mask[~band], omask[~band])
+    if n >= 1000:
+        assert 0.5 < mask.mean() < 1.0
+        # truth: the median triangulated point is close to its generating point
+        ok = mask.astype(bool)
+        d = np.linalg.norm(X[ok] - s["X"][ok], axis=1) / np.linalg.norm(s["X"][ok], axis=1)
+        assert np.median(d) < 0.05
+
+
+def test_triangulate_relative_pose_arguments(ctx, oracle):
+    """R, t are separate arguments: in the reference's VO mode they are the relative pose
+    while the projection matrices are absolute (Source Files/app_solver.cpp:288)."""
+    from sfm_amd import synth
+
+    s = synth.triangulation_set(500, seed=3)
+    R2 = synth.rot_y(-2.0)
+    t2 = np.array([0.3, -0.1, 0.2])
+    args = (s["K"], s["prev_pose"], s["curr_pose"], R2, t2, s["p1"], s["p2"])
+    X, _, mask, err = ctx.triangulate(*args)
+    oX, _, omask, oerr = oracle.triangulate(*args)
+    np.testing.assert_allclose(X, oX, rtol=1e-9)
+    np.testing.assert_allclose(err, oerr, rtol=1e-6)
+    np.testing.assert_array_equal(mask, omask)
+
+
+def test_triangulate_exact_projections_known_answer(ctx):
+    from sfm_amd import synth
+
+    s = synth.triangulation_set(2000, seed=11, sigma=0.0, outliers=0.0)
+    X, _, mask, err = ctx.triangulate(s["K"], s["prev_pose"], s["curr_pose"], s["R"], s["t"],
+                                      s["p1"], s["p2"])
+    rel = np.linalg.norm(X - s["X"], axis=1) / np.linalg.norm(s["X"], axis=1)
+    assert rel.max() < 5e-3  # float32 pixel coordinates bound the accuracy
+    assert mask.all() and err.max() < 1e-2
+
+
+def test_triangulate_empty_and_degenerate(ctx):
+    from sfm_amd import synth
+
+    s = synth.triangulation_set(4, seed=1)
+    X, rgb, mask, err = ctx.triangulate(s["K"], s["prev_pose"], s["curr_pose"], s["R"], s["t"],
+                                        np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32))
+    assert X.shape == (0, 3) and mask.shape == (0,)
+    # identical cameras: the system is rank deficient; outputs must still be finite or inf,
+    # never a fault, and the mask must reject points at infinity
+    X, _, mask, _ = ctx.triangulate(s["K"], s["prev_pose"], s["prev_pose"], np.eye(3), np.zeros(3),
+                                    s["p1"], s["p1"])
+    assert X.shape == (4, 3)
+
+
+def test_triangulate_mirror_class(ctx, oracle):
+    import sfm_amd
+    from sfm_amd import synth
+
+    s = synth.triangulation_set(300, seed=21)
+    cam = sfm_amd.CameraParameters(s["K"] * 2.0, None, downSample=2.0)
+    np.testing.assert_array_equal(cam.K33d, s["K"])
+    rec = sfm_amd.Reconstruction("ITERATIVE", "", 0.0, 1e-4, 250.0, 3.0, True, ctx=ctx)
+    img = np.full((720, 1280, 3), 7, np.uint8)
+    pts3d, rgb, mask = rec.triangulateCloud(cam, s["p1"], s["p2"], img, s["prev_pose"],
+                                            s["curr_pose"], s["R"], s["t"])
+    oX, _, omask, _ = oracle.triangulate(s["K"], s["prev_pose"], s["curr_pose"], s["R"], s["t"],
+                                         s["p1"], s["p2"])
+    np.testing.assert_allclose(pts3d, oX, rtol=1e-9)
+    assert (rgb == 7).all() and mask.dtype == bool
+    np.testing.assert_array_equal(mask, omask.astype(bool))
+    assert rec.triangulateCloud(cam, [], [], img, s["prev_pose"], s["curr_pose"], s["R"],
+                                s["t"])[0].shape == (0, 3)
+    with pytest.raises(sfm_amd.capi.SfmError):
+        sfm_amd.Reconstruction("DLT", ctx=ctx).triangulateCloud(
+            cam, s["p1"], s["p2"], img, s["prev_pose"], s["curr_pose"], s["R"], s["t"])
