@@ -121,8 +121,8 @@ int sfm_match_pairs_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames
                         size_t frame_stride, int rows_per_frame, const int32_t* d_counts,
                         int d, const int32_t* d_pairs, int n_pairs, float ratio,
                         sfm_dmatch* d_matches, int cap, int32_t* d_match_counts);
-/* Workspace bytes sfm_match_pairs_dev needs for these sizes. */
-size_t sfm_match_pairs_workspace(int norm, int rows_per_frame, int d, int n_pairs);
+/* Workspace bytes sfm_match_pairs_dev needs for these sizes (sfm_ctx_reserve). */
+size_t sfm_match_pairs_workspace(int norm, int n_frames, int rows_per_frame, int d, int n_pairs);
 
 /* ---- pyramidal Lucas-Kanade --------------------------------------------- */
 

@@ -173,9 +173,10 @@ class Context:
             C.c_float(ratio), _ptr(d_matches), C.c_int(cap), _ptr(d_match_counts)))
 
     @staticmethod
-    def match_pairs_workspace(norm, rows_per_frame, d, n_pairs):
-        return int(lib().sfm_match_pairs_workspace(C.c_int(norm), C.c_int(rows_per_frame),
-                                                   C.c_int(d), C.c_int(n_pairs)))
+    def match_pairs_workspace(norm, n_frames, rows_per_frame, d, n_pairs):
+        return int(lib().sfm_match_pairs_workspace(C.c_int(norm), C.c_int(n_frames),
+                                                   C.c_int(rows_per_frame), C.c_int(d),
+                                                   C.c_int(n_pairs)))
 
     # ---- Lucas-Kanade -----------------------------------------------------
     def pyrlk(self, prev, curr, prev_pts, win=(21, 21), max_level=3,

@@ -10,11 +10,11 @@ int launch_ratio_compact(sfm_ctx* ctx, const int32_t* d_idx, const float* d_dist
                          float ratio, sfm_dmatch* d_out, int32_t* d_count);
 int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_stride,
                 const float* d_t, int nt, size_t t_stride, int dim, int32_t* d_idx, float* d_dist);
-int l2_match_pairs_dev(sfm_ctx* ctx, int squared, const float* d_desc, size_t frame_stride,
-                       int rows_per_frame, const int32_t* d_counts, int dim,
-                       const int32_t* d_pairs, int n_pairs, float ratio, sfm_dmatch* d_matches,
-                       int cap, int32_t* d_match_counts);
-size_t l2_match_pairs_workspace(int rows_per_frame, int dim, int n_pairs);
+int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_frames,
+                        size_t frame_stride, int rows_per_frame, const int32_t* d_counts, int dim,
+                        const int32_t* d_pairs, int n_pairs, float ratio, sfm_dmatch* d_matches,
+                        int cap, int32_t* d_match_counts, int pair_chunk);
+size_t l2_match_pairs_workspace(int n_frames, int rows_per_frame, int dim, int n_pairs);
 }  // namespace sfm
 
 using namespace sfm;
@@ -26,6 +26,7 @@ constexpr int kMaxHammingBytes = 256;
 // Pairs handled per launch sequence: bounds the key workspace (2 problems per
 // pair, 8 bytes per query row and split).
 constexpr int kPairChunk = 4096;
+constexpr int kL2PairChunk = 256;  // float candidates take 16 bytes per query row and split
 
 int check_common(sfm_ctx* ctx, int norm, int n_a, int n_b, int d) {
     if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
@@ -212,13 +213,16 @@ int sfm_ratio_matches(sfm_ctx* ctx, int norm, const void* q, int nq, size_t q_st
     return SFM_OK;
 }
 
-size_t sfm_match_pairs_workspace(int norm, int rows_per_frame, int d, int n_pairs) {
-    if (rows_per_frame <= 0 || d <= 0 || n_pairs <= 0) return 0;
+size_t sfm_match_pairs_workspace(int norm, int n_frames, int rows_per_frame, int d, int n_pairs) {
+    if (n_frames <= 0 || rows_per_frame <= 0 || d <= 0 || n_pairs <= 0) return 0;
     const int chunk = std::min(n_pairs, kPairChunk);
-    if (norm != SFM_NORM_HAMMING) return l2_match_pairs_workspace(rows_per_frame, d, chunk);
+    if (norm != SFM_NORM_HAMMING)
+        return l2_match_pairs_workspace(n_frames, rows_per_frame, d, std::min(chunk, kL2PairChunk));
     sfm_ctx fake;
     KnnPlan plan = make_knn_plan(&fake, norm, d, rows_per_frame, rows_per_frame, 2 * chunk);
-    return hamming_pairs_bytes(plan, chunk);
+    const bool packed = d == plan.row_words * 4;
+    return hamming_pairs_bytes(plan, chunk) +
+           (packed ? 0 : align_up((size_t)n_frames * rows_per_frame * plan.row_words * 4, 256));
 }
 
 int sfm_match_pairs_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames,
@@ -232,17 +236,10 @@ int sfm_match_pairs_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames
     if (!d_desc || !d_pairs || !d_matches || !d_match_counts)
         return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
     SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if (norm != SFM_NORM_HAMMING) {
-        for (int p0 = 0; p0 < n_pairs; p0 += kPairChunk) {
-            const int np = std::min(kPairChunk, n_pairs - p0);
-            SFM_RETURN_IF(l2_match_pairs_dev(ctx, norm == SFM_NORM_L2SQR,
-                                             static_cast<const float*>(d_desc), frame_stride,
-                                             rows_per_frame, d_counts, d, d_pairs + 2 * (size_t)p0,
-                                             np, ratio, d_matches + (size_t)p0 * cap, cap,
-                                             d_match_counts + p0));
-        }
-        return SFM_OK;
-    }
+    if (norm != SFM_NORM_HAMMING)
+        return l2_match_frames_dev(ctx, norm == SFM_NORM_L2SQR, static_cast<const float*>(d_desc),
+                                   n_frames, frame_stride, rows_per_frame, d_counts, d, d_pairs,
+                                   n_pairs, ratio, d_matches, cap, d_match_counts, kL2PairChunk);
     if (frame_stride < (size_t)rows_per_frame * d)
         return set_error(ctx, SFM_E_INVALID, "frame stride smaller than a frame");
 

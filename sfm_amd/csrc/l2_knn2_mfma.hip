@@ -1,13 +1,546 @@
-// placeholder: replaced by the fp32 MFMA kernel
+// Brute-force L2 2-nearest-neighbour search for float descriptors on the fp32
+// matrix cores of gfx950.
+//
+// Replaces cv::BFMatcher(NORM_L2 / NORM_L2SQR)::knnMatch(q, t, out, 2) as called
+// from DescriptorMatcher::ratioMaches (Source Files/feature_processing.cpp:121)
+// for the "BRUTEFORCE" and "BRUTEFORCE_SL2" matcher types (:111, :115).
+//
+// Two passes.
+//   1. Candidate pass (MFMA).  ||q - t||^2 - ||q||^2 = ||t||^2 - 2 q.t is formed as a
+//      dense contraction on v_mfma_f32_32x32x2_f32: the train tile is the A
+//      operand (rows = train), the query tile the B operand (columns = queries),
+//      so each lane's accumulator registers hold 16 train candidates of ONE query
+//      and the running best-two list of that query lives in the lane's registers
+//      with no cross-lane traffic.  The queries of a wave (pre-scaled by -2, an
+//      exact scaling) stay in VGPRs for the whole kernel; train tiles are copied
+//      global -> LDS by global_load_lds (XOR-swizzled through the source
+//      address so that the ds_read_b128 fragment reads are conflict-free); the
+//      accumulators are initialised with ||t||^2 straight from LDS, so the
+//      accumulator is the ranking key when the k-loop ends.  Every (lane half,
+//      train split) keeps its own best two, which are written out as candidates.
+//   2. Re-score pass.  For every candidate the squared distance is recomputed
+//      as the sequential float sum  d += (a-b)*(a-b)  (the scalar order of
+//      OpenCV's normL2Sqr), the square root is taken for NORM_L2, and the best
+//      two are chosen by (distance, train index).  The results therefore do not
+//      depend on the rounding of the MFMA form, unless three or more train rows
+//      of one candidate list lie within fp32 rounding of the second-best
+//      distance.
+#include <cfloat>
+
 #include "sfm_internal.h"
+
 namespace sfm {
-int l2_knn2_dev(sfm_ctx* ctx, int, const float*, int, size_t, const float*, int, size_t, int,
-                int32_t*, float*) {
-    return set_error(ctx, SFM_E_UNSUPPORTED, "L2 matching not built");
+
+int launch_ratio_cross_knn(sfm_ctx* ctx, const int32_t* d_knn_idx, const float* d_knn_dist,
+                           int rows_max, const int32_t* d_counts, int rows_uniform,
+                           const int32_t* d_pairs, int n_pairs, float ratio, int32_t* d_best,
+                           float* d_best_dist, sfm_dmatch* d_matches, int cap,
+                           int32_t* d_match_counts);
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBlock = 256;
+constexpr int kTileRows = 64;   // train rows per LDS tile (two 32-row MFMA tiles)
+constexpr int kMaxSplits = 16;  // 4 candidates per split and query, 64 per query at most
+
+struct L2Args {
+    const float* q_base;  // packed rows of K floats
+    const float* t_base;
+    const float* t_norms;  // ||t||^2 per packed train row, same frame layout (rows_cap per frame)
+    size_t frame_floats;   // floats per frame in q_base / t_base
+    int rows_cap;          // rows per frame in the norm array and the candidate array
+    const int32_t* counts;
+    int nq_uniform, nt_uniform;
+    const int32_t* pairs;
+    int n_groups;
+    int qtiles, splits, blocks_per_group;
+    int32_t* cand;  // [problem][split][rows_cap][4]
+};
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gptr,
+        (__attribute__((address_space(3))) void*)lptr, 16, 0, 0);
 }
-int l2_match_pairs_dev(sfm_ctx* ctx, int, const float*, size_t, int, const int32_t*, int,
-                       const int32_t*, int, float, sfm_dmatch*, int, int32_t*) {
-    return set_error(ctx, SFM_E_UNSUPPORTED, "L2 matching not built");
+
+template <int K, int NT>
+__global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
+    constexpr int kChunksPerRow = K / 4;             // 16-byte chunks
+    constexpr int kTileFloats = kTileRows * K;
+    constexpr int kQPerWave = 32 * NT;
+    constexpr int kQPerBlock = 4 * kQPerWave;
+    // one array: [2 tiles][kTileFloats] then [2][64] norms
+    __shared__ __attribute__((aligned(16))) float lds[2 * kTileFloats + 2 * kTileRows];
+    float* norm_lds = lds + 2 * kTileFloats;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int g = blockIdx.x / a.blocks_per_group, inner = blockIdx.x % a.blocks_per_group;
+    const int per_dir = a.qtiles * a.splits;
+    const int dir = inner / per_dir;
+    const int qtile = (inner % per_dir) / a.splits;
+    const int split = inner % a.splits;
+    int qf = 0, tf = 0, problem = 0;
+    if (a.pairs) {
+        const int fa = a.pairs[2 * g], fb = a.pairs[2 * g + 1];
+        qf = dir ? fb : fa;
+        tf = dir ? fa : fb;
+        problem = 2 * g + dir;
+    }
+    const int nq = a.counts ? a.counts[qf] : a.nq_uniform;
+    const int nt = a.counts ? a.counts[tf] : a.nt_uniform;
+    const int q0 = qtile * kQPerBlock;
+    if (q0 >= nq) return;
+    const float* qrows = a.q_base + (size_t)qf * a.frame_floats;
+    const float* trows = a.t_base + (size_t)tf * a.frame_floats;
+    const float* tnorm = a.t_norms + (size_t)tf * a.rows_cap;
+
+    // B operand: this lane's query columns, scaled by -2, resident for the whole kernel.
+    // Element [n][m][s] is dimension 8m + 4*lh + s of query q0 + wave*kQPerWave + 32n + li.
+    float qreg[NT][K / 8][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int qi = q0 + wave * kQPerWave + 32 * n + li;
+        const floatx4* src = reinterpret_cast<const floatx4*>(qrows + (size_t)(qi < nq ? qi : 0) * K);
+#pragma unroll
+        for (int m = 0; m < K / 8; ++m) {
+            floatx4 v = src[2 * m + lh];
+            if (qi >= nq) v = floatx4{0.f, 0.f, 0.f, 0.f};
+            qreg[n][m][0] = -2.f * v.x;
+            qreg[n][m][1] = -2.f * v.y;
+            qreg[n][m][2] = -2.f * v.z;
+            qreg[n][m][3] = -2.f * v.w;
+        }
+    }
+    float best0[NT], best1[NT];
+    int bidx0[NT], bidx1[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        best0[n] = best1[n] = FLT_MAX;
+        bidx0[n] = bidx1[n] = -1;
+    }
+
+    const int chunk = (nt + a.splits - 1) / a.splits;
+    const int t_begin = split * chunk;
+    const int t_end = min(nt, t_begin + chunk);
+    const int ntiles = t_end > t_begin ? (t_end - t_begin + kTileRows - 1) / kTileRows : 0;
+
+    // global -> LDS copy of one tile: LDS position p (16-byte chunks, linear) holds chunk
+    // (p % cpr) ^ (row & 15) of row p / cpr; each wave instruction fills 64 positions.
+    auto stage = [&](int k, int buf) {
+        const int tbase = t_begin + k * kTileRows;
+        float* dst = lds + buf * kTileFloats;
+#pragma unroll
+        for (int it = 0; it < kChunksPerRow / 4; ++it) {
+            const int instr = wave * (kChunksPerRow / 4) + it;  // kChunksPerRow instructions per tile
+            const int p = instr * 64 + lane;
+            const int row = p / kChunksPerRow, cpos = p % kChunksPerRow;
+            const int c = cpos ^ (row & 15);
+            int trow = tbase + row;
+            trow = trow < nt ? trow : nt - 1;  // clamped rows are masked by an infinite norm
+            glds16(trows + (size_t)trow * K + c * 4, dst + instr * 256);
+        }
+        if (tid < kTileRows) {
+            const int trow = tbase + tid;
+            norm_lds[buf * kTileRows + tid] = trow < t_end ? tnorm[trow] : INFINITY;
+        }
+    };
+
+    if (ntiles > 0) stage(0, 0);
+    __syncthreads();
+
+    for (int k = 0; k < ntiles; ++k) {
+        const int buf = k & 1;
+        if (k + 1 < ntiles) stage(k + 1, buf ^ 1);
+        const float* tile = lds + buf * kTileFloats;
+        const float* nrm = norm_lds + buf * kTileRows;
+
+        floatx16 acc[2][NT];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            // accumulator register r of this lane is train row 32mt + 8(r>>2) + 4lh + (r&3)
+            floatx16 init;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const floatx4 v = *reinterpret_cast<const floatx4*>(nrm + 32 * mt + 8 * gq + 4 * lh);
+                init[4 * gq + 0] = v.x;
+                init[4 * gq + 1] = v.y;
+                init[4 * gq + 2] = v.z;
+                init[4 * gq + 3] = v.w;
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[mt][n] = init;
+        }
+
+#pragma unroll
+        for (int m = 0; m < K / 8; ++m) {
+            floatx4 av[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int row = 32 * mt + li;
+                const int cpos = (2 * m + lh) ^ (row & 15);
+                av[mt] = *reinterpret_cast<const floatx4*>(tile + row * K + cpos * 4);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[mt][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][s], qreg[n][m][s],
+                                                                          acc[mt][n], 0, 0, 0);
+        }
+
+        // keep the two smallest keys per lane and query tile; candidates arrive in
+        // ascending train index, so strict comparisons keep the lower index on ties
+        const int tbase = t_begin + k * kTileRows;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const floatx16& c = acc[mt][n];
+                    const float lo = fminf(fminf(c[4 * gq], c[4 * gq + 1]),
+                                           fminf(c[4 * gq + 2], c[4 * gq + 3]));
+                    if (__any(lo < best1[n])) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float key = c[4 * gq + r];
+                            const int ti = tbase + 32 * mt + 8 * gq + 4 * lh + r;
+                            if (key < best1[n]) {
+                                if (key < best0[n]) {
+                                    best1[n] = best0[n];
+                                    bidx1[n] = bidx0[n];
+                                    best0[n] = key;
+                                    bidx0[n] = ti;
+                                } else {
+                                    best1[n] = key;
+                                    bidx1[n] = ti;
+                                }
+                            }
+                        }
+                    }
+                }
+        __syncthreads();
+    }
+
+    int32_t* cand = a.cand + (((size_t)problem * a.splits + split) * a.rows_cap) * 4;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int qi = q0 + wave * kQPerWave + 32 * n + li;
+        if (qi < nq) {
+            cand[(size_t)qi * 4 + 2 * lh] = bidx0[n];
+            cand[(size_t)qi * 4 + 2 * lh + 1] = bidx1[n];
+        }
+    }
 }
-size_t l2_match_pairs_workspace(int, int, int) { return 0; }
+
+// Zero-padded repack of float rows into rows of K floats, and ||row||^2.
+__global__ void l2_pack_kernel(const uint8_t* __restrict__ src, int n, size_t src_stride, int dim,
+                               float* __restrict__ dst, int K, float* __restrict__ norms) {
+    const int row = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float* s = reinterpret_cast<const float*>(src + (size_t)row * src_stride);
+    float acc = 0.f;
+    for (int j = lane; j < K; j += 64) {
+        const float v = j < dim ? s[j] : 0.f;
+        if (dst) dst[(size_t)row * K + j] = v;
+        acc += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) norms[row] = acc;
+}
+
+struct RescoreArgs {
+    const float* q_base;
+    const float* t_base;
+    size_t frame_floats;
+    int rows_cap;
+    const int32_t* counts;
+    int nq_uniform, nt_uniform;
+    const int32_t* pairs;
+    int splits;
+    int K, dim;
+    int squared;
+    const int32_t* cand;
+    int32_t* knn_idx;  // [problem][rows_cap][2]
+    float* knn_dist;
+};
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(v, o);
+        v = other < v ? other : v;
+    }
+    return v;
+}
+
+// One wave per (problem, query): lane c re-scores candidate c.
+__global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int problem = blockIdx.y;
+    const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    int qf = 0, tf = 0;
+    if (a.pairs) {
+        const int gp = problem >> 1, dir = problem & 1;
+        const int fa = a.pairs[2 * gp], fb = a.pairs[2 * gp + 1];
+        qf = dir ? fb : fa;
+        tf = dir ? fa : fb;
+    }
+    const int nq = a.counts ? a.counts[qf] : a.nq_uniform;
+    if (q >= nq) return;  // wave-uniform
+    const float* qrow = a.q_base + (size_t)qf * a.frame_floats + (size_t)q * a.K;
+    const float* trows = a.t_base + (size_t)tf * a.frame_floats;
+    const int ncand = a.splits * 4;
+    int ti = -1;
+    if (lane < ncand) {
+        const int split = lane >> 2, slot = lane & 3;
+        ti = a.cand[((((size_t)problem * a.splits + split) * a.rows_cap) + q) * 4 + slot];
+    }
+    unsigned long long key = ~0ull;
+    if (ti >= 0) {
+        const float* trow = trows + (size_t)ti * a.K;
+        float d = 0.f;
+        for (int j = 0; j < a.dim; ++j) {  // scalar order of OpenCV's normL2Sqr
+            const float v = qrow[j] - trow[j];
+            d += v * v;
+        }
+        if (!a.squared) d = sqrtf(d);  // batchDistL2_32f
+        key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)ti;
+    }
+    const unsigned long long k0 = wave_min_u64(key);
+    const unsigned long long k1 = wave_min_u64(key == k0 ? ~0ull : key);
+    if (lane == 0) {
+        const size_t o = ((size_t)problem * a.rows_cap + q) * 2;
+        a.knn_idx[o] = k0 == ~0ull ? -1 : (int32_t)(k0 & 0xFFFFFFFFu);
+        a.knn_idx[o + 1] = k1 == ~0ull ? -1 : (int32_t)(k1 & 0xFFFFFFFFu);
+        a.knn_dist[o] = k0 == ~0ull ? FLT_MAX : __uint_as_float((unsigned)(k0 >> 32));
+        a.knn_dist[o + 1] = k1 == ~0ull ? FLT_MAX : __uint_as_float((unsigned)(k1 >> 32));
+    }
+}
+
+struct L2Plan {
+    int K, NT, q_per_block, qtiles, splits;
+};
+
+int make_l2_plan(const sfm_ctx* ctx, int dim, int nq_max, int nt_max, int n_problems, L2Plan* p) {
+    if (dim <= 64) {
+        p->K = 64;
+        p->NT = 2;
+    } else if (dim <= 128) {
+        p->K = 128;
+        p->NT = 2;
+    } else if (dim <= 256) {
+        p->K = 256;
+        p->NT = 1;
+    } else {
+        return SFM_E_UNSUPPORTED;
+    }
+    p->q_per_block = 4 * 32 * p->NT;
+    p->qtiles = (nq_max + p->q_per_block - 1) / p->q_per_block;
+    const long want = 4L * ctx->num_cus;
+    const long blocks = (long)p->qtiles * n_problems;
+    int splits = (int)((want + blocks - 1) / blocks);
+    const int max_splits = (nt_max + 2 * kTileRows - 1) / (2 * kTileRows);
+    if (splits > max_splits) splits = max_splits;
+    if (splits > kMaxSplits) splits = kMaxSplits;
+    if (splits < 1) splits = 1;
+    p->splits = splits;
+    return SFM_OK;
+}
+
+template <int K, int NT>
+int launch_candidates(sfm_ctx* ctx, const L2Args& a, long grid) {
+    hipLaunchKernelGGL((l2_candidates_kernel<K, NT>), dim3((unsigned)grid), dim3(kBlock), 0,
+                       ctx->stream, a);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+// Candidate + re-score passes over packed data; writes knn_idx/knn_dist [problem][rows_cap][2].
+int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const float* q_base,
+                  const float* t_base, const float* t_norms, size_t frame_floats, int rows_cap,
+                  const int32_t* d_counts, int nq_uniform, int nt_uniform, const int32_t* d_pairs,
+                  int n_problems, int32_t* cand, int32_t* knn_idx, float* knn_dist) {
+    L2Args a{};
+    a.q_base = q_base;
+    a.t_base = t_base;
+    a.t_norms = t_norms;
+    a.frame_floats = frame_floats;
+    a.rows_cap = rows_cap;
+    a.counts = d_counts;
+    a.nq_uniform = nq_uniform;
+    a.nt_uniform = nt_uniform;
+    a.pairs = d_pairs;
+    a.n_groups = d_pairs ? n_problems / 2 : 1;
+    a.qtiles = plan.qtiles;
+    a.splits = plan.splits;
+    a.blocks_per_group = (d_pairs ? 2 : 1) * plan.qtiles * plan.splits;
+    a.cand = cand;
+    const long grid = (long)a.n_groups * a.blocks_per_group;
+    if (grid <= 0) return SFM_OK;
+    if (grid > 0x7fffffffL) return set_error(ctx, SFM_E_INVALID, "knn launch too large");
+    if (plan.K == 64)
+        SFM_RETURN_IF((launch_candidates<64, 2>(ctx, a, grid)));
+    else if (plan.K == 128)
+        SFM_RETURN_IF((launch_candidates<128, 2>(ctx, a, grid)));
+    else
+        SFM_RETURN_IF((launch_candidates<256, 1>(ctx, a, grid)));
+
+    RescoreArgs r{};
+    r.q_base = q_base;
+    r.t_base = t_base;
+    r.frame_floats = frame_floats;
+    r.rows_cap = rows_cap;
+    r.counts = d_counts;
+    r.nq_uniform = nq_uniform;
+    r.nt_uniform = nt_uniform;
+    r.pairs = d_pairs;
+    r.splits = plan.splits;
+    r.K = plan.K;
+    r.dim = dim;
+    r.squared = squared;
+    r.cand = cand;
+    r.knn_idx = knn_idx;
+    r.knn_dist = knn_dist;
+    const int nq_max = d_counts ? rows_cap : nq_uniform;
+    const dim3 rgrid((nq_max + kBlock / 64 - 1) / (kBlock / 64), n_problems);
+    hipLaunchKernelGGL(l2_rescore_kernel, rgrid, dim3(kBlock), 0, ctx->stream, r);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+int l2_pack(sfm_ctx* ctx, const void* src, int n, size_t stride_bytes, int dim, float* dst, int K,
+            float* norms) {
+    if (n <= 0) return SFM_OK;
+    hipLaunchKernelGGL(l2_pack_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream,
+                       static_cast<const uint8_t*>(src), n, stride_bytes, dim, dst, K, norms);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+}  // namespace
+
+int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_stride,
+                const float* d_t, int nt, size_t t_stride, int dim, int32_t* d_idx, float* d_dist) {
+    if (q_stride < (size_t)dim * 4 || (nt > 0 && t_stride < (size_t)dim * 4))
+        return set_error(ctx, SFM_E_INVALID, "row stride smaller than the row");
+    if ((q_stride & 3) || (t_stride & 3) || (reinterpret_cast<uintptr_t>(d_q) & 3) ||
+        (reinterpret_cast<uintptr_t>(d_t) & 3))
+        return set_error(ctx, SFM_E_INVALID, "float rows must be 4-byte aligned");
+    L2Plan plan;
+    if (make_l2_plan(ctx, dim, nq, nt, 1, &plan) != SFM_OK)
+        return set_error(ctx, SFM_E_UNSUPPORTED, "float descriptors above 256 dimensions unsupported");
+    const int K = plan.K;
+    const int rows_cap = nq > nt ? nq : nt;
+    Carver sz(nullptr);
+    sz.take<float>((size_t)nq * K);
+    sz.take<float>((size_t)(nt > 0 ? nt : 1) * K);
+    sz.take<float>((size_t)rows_cap);
+    sz.take<float>((size_t)rows_cap);
+    sz.take<int32_t>((size_t)plan.splits * rows_cap * 4);
+    sz.take<int32_t>((size_t)rows_cap * 2);
+    sz.take<float>((size_t)rows_cap * 2);
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
+    Carver c(ws);
+    float* qp = c.take<float>((size_t)nq * K);
+    float* tp = c.take<float>((size_t)(nt > 0 ? nt : 1) * K);
+    float* qn = c.take<float>((size_t)rows_cap);
+    float* tn = c.take<float>((size_t)rows_cap);
+    int32_t* cand = c.take<int32_t>((size_t)plan.splits * rows_cap * 4);
+    int32_t* kidx = c.take<int32_t>((size_t)rows_cap * 2);
+    float* kdist = c.take<float>((size_t)rows_cap * 2);
+    SFM_RETURN_IF(l2_pack(ctx, d_q, nq, q_stride, dim, qp, K, qn));
+    SFM_RETURN_IF(l2_pack(ctx, d_t, nt, t_stride, dim, tp, K, tn));
+    SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, qp, tp, tn, 0, rows_cap, nullptr, nq, nt,
+                                nullptr, 1, cand, kidx, kdist));
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, kidx, sizeof(int32_t) * 2 * nq, hipMemcpyDeviceToDevice,
+                                      ctx->stream));
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_dist, kdist, sizeof(float) * 2 * nq, hipMemcpyDeviceToDevice,
+                                      ctx->stream));
+    return SFM_OK;
+}
+
+namespace {
+struct L2PairBuffers {
+    float* packed;
+    float* norms;
+    int32_t* cand;
+    int32_t* kidx;
+    float* kdist;
+    int32_t* best;
+    float* best_dist;
+};
+void l2_pairs_carve(Carver& c, const L2Plan& plan, int n_frames, int rows, int n_pairs,
+                    L2PairBuffers* b) {
+    b->packed = c.take<float>((size_t)n_frames * rows * plan.K);
+    b->norms = c.take<float>((size_t)n_frames * rows);
+    const size_t nprob = 2 * (size_t)n_pairs;
+    b->cand = c.take<int32_t>(nprob * plan.splits * rows * 4);
+    b->kidx = c.take<int32_t>(nprob * rows * 2);
+    b->kdist = c.take<float>(nprob * rows * 2);
+    b->best = c.take<int32_t>(nprob * rows);
+    b->best_dist = c.take<float>(nprob * rows);
+}
+}  // namespace
+
+size_t l2_match_pairs_workspace(int n_frames, int rows_per_frame, int dim, int n_pairs) {
+    sfm_ctx fake;
+    L2Plan plan;
+    if (make_l2_plan(&fake, dim, rows_per_frame, rows_per_frame, 2 * n_pairs, &plan) != SFM_OK)
+        return 0;
+    Carver c(nullptr);
+    L2PairBuffers b;
+    l2_pairs_carve(c, plan, n_frames, rows_per_frame, n_pairs, &b);
+    return c.total();
+}
+
+// Every frame is repacked (zero-padded to K floats, norms computed) on each call.
+int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_frames,
+                        size_t frame_stride, int rows_per_frame, const int32_t* d_counts, int dim,
+                        const int32_t* d_pairs, int n_pairs, float ratio, sfm_dmatch* d_matches,
+                        int cap, int32_t* d_match_counts, int pair_chunk) {
+    if (frame_stride < (size_t)rows_per_frame * dim * 4)
+        return set_error(ctx, SFM_E_INVALID, "frame stride smaller than a frame");
+    if ((frame_stride & 3) || (reinterpret_cast<uintptr_t>(d_desc) & 3))
+        return set_error(ctx, SFM_E_INVALID, "float rows must be 4-byte aligned");
+    const int chunk = n_pairs < pair_chunk ? n_pairs : pair_chunk;
+    L2Plan plan;
+    if (make_l2_plan(ctx, dim, rows_per_frame, rows_per_frame, 2 * chunk, &plan) != SFM_OK)
+        return set_error(ctx, SFM_E_UNSUPPORTED, "float descriptors above 256 dimensions unsupported");
+    Carver sz(nullptr);
+    L2PairBuffers b;
+    l2_pairs_carve(sz, plan, n_frames, rows_per_frame, chunk, &b);
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
+    Carver c(ws);
+    l2_pairs_carve(c, plan, n_frames, rows_per_frame, chunk, &b);
+    for (int f = 0; f < n_frames; ++f)
+        SFM_RETURN_IF(l2_pack(ctx, reinterpret_cast<const uint8_t*>(d_desc) + f * frame_stride,
+                              rows_per_frame, (size_t)dim * 4, dim,
+                              b.packed + (size_t)f * rows_per_frame * plan.K, plan.K,
+                              b.norms + (size_t)f * rows_per_frame));
+    for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
+        const int np = chunk < n_pairs - p0 ? chunk : n_pairs - p0;
+        const int32_t* pairs = d_pairs + 2 * (size_t)p0;
+        SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, b.packed, b.packed, b.norms,
+                                    (size_t)rows_per_frame * plan.K, rows_per_frame, d_counts,
+                                    rows_per_frame, rows_per_frame, pairs, 2 * np, b.cand, b.kidx,
+                                    b.kdist));
+        SFM_RETURN_IF(launch_ratio_cross_knn(ctx, b.kidx, b.kdist, rows_per_frame, d_counts,
+                                             rows_per_frame, pairs, np, ratio, b.best, b.best_dist,
+                                             d_matches + (size_t)p0 * cap, cap,
+                                             d_match_counts + p0));
+    }
+    return SFM_OK;
+}
+
 }  // namespace sfm

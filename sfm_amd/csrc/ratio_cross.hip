@@ -18,7 +18,9 @@ constexpr int kIdxBits = 18;
 constexpr int kThreads = 1024;
 
 struct CrossArgs {
-    const uint2* keys;
+    const uint2* keys;        // Hamming: per-split packed keys; nullptr -> use knn_idx/knn_dist
+    const int32_t* knn_idx;   // [2*n_pairs][rows_max][2]
+    const float* knn_dist;
     int splits;
     int rows_max;
     const int32_t* counts;
@@ -52,20 +54,33 @@ __global__ __launch_bounds__(kThreads) void ratio_cross_kernel(CrossArgs a) {
         const int nq = dir ? n_curr : n_prev;
         const int nt = dir ? n_prev : n_curr;
         const size_t problem = 2 * (size_t)pair + dir;
-        const uint2* keys = a.keys + problem * a.splits * (size_t)a.rows_max;
+        const uint2* keys = a.keys ? a.keys + problem * a.splits * (size_t)a.rows_max : nullptr;
         for (int q = tid; q < nq; q += kThreads) {
-            uint32_t m1 = kNoKey, m2 = kNoKey;
-            for (int s = 0; s < a.splits; ++s) {
-                const uint2 k = keys[(size_t)s * a.rows_max + q];
-                m2 = med3_u32(m1, m2, k.x);
-                m1 = min(m1, k.x);
-                m2 = med3_u32(m1, m2, k.y);
-                m1 = min(m1, k.y);
+            float d0, d1;
+            int32_t i0, i1;
+            if (a.keys) {
+                uint32_t m1 = kNoKey, m2 = kNoKey;
+                for (int s = 0; s < a.splits; ++s) {
+                    const uint2 k = keys[(size_t)s * a.rows_max + q];
+                    m2 = med3_u32(m1, m2, k.x);
+                    m1 = min(m1, k.x);
+                    m2 = med3_u32(m1, m2, k.y);
+                    m1 = min(m1, k.y);
+                }
+                d0 = (float)(m1 >> kIdxBits);
+                d1 = (float)(m2 >> kIdxBits);
+                i0 = m1 == kNoKey ? -1 : (int32_t)(m1 & mask);
+                i1 = m2 == kNoKey ? -1 : (int32_t)(m2 & mask);
+            } else {
+                const size_t o = (problem * a.rows_max + q) * 2;
+                i0 = a.knn_idx[o];
+                i1 = a.knn_idx[o + 1];
+                d0 = a.knn_dist[o];
+                d1 = a.knn_dist[o + 1];
             }
-            const float d0 = (float)(m1 >> kIdxBits), d1 = (float)(m2 >> kIdxBits);
             // feature_processing.cpp:127, float * float, strict <
-            const bool pass = nt >= 2 && d0 < a.ratio * d1;
-            a.best[problem * a.rows_max + q] = pass ? (int32_t)(m1 & mask) : -1;
+            const bool pass = nt >= 2 && i1 >= 0 && d0 < a.ratio * d1;
+            a.best[problem * a.rows_max + q] = pass ? i0 : -1;
             a.best_dist[problem * a.rows_max + q] = d0;
         }
     }
@@ -171,6 +186,33 @@ int launch_ratio_cross(sfm_ctx* ctx, const KnnPlan& plan, const uint32_t* d_keys
     a.counts = d_counts;
     a.n_prev_uniform = rows_uniform_prev;
     a.n_curr_uniform = rows_uniform_curr;
+    a.pairs = d_pairs;
+    a.ratio = ratio;
+    a.best = d_best;
+    a.best_dist = d_best_dist;
+    a.matches = d_matches;
+    a.cap = cap;
+    a.match_counts = d_match_counts;
+    hipLaunchKernelGGL(ratio_cross_kernel, dim3(n_pairs), dim3(kThreads), 0, ctx->stream, a);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+int launch_ratio_cross_knn(sfm_ctx* ctx, const int32_t* d_knn_idx, const float* d_knn_dist,
+                           int rows_max, const int32_t* d_counts, int rows_uniform,
+                           const int32_t* d_pairs, int n_pairs, float ratio, int32_t* d_best,
+                           float* d_best_dist, sfm_dmatch* d_matches, int cap,
+                           int32_t* d_match_counts) {
+    if (n_pairs <= 0) return SFM_OK;
+    CrossArgs a{};
+    a.keys = nullptr;
+    a.knn_idx = d_knn_idx;
+    a.knn_dist = d_knn_dist;
+    a.splits = 1;
+    a.rows_max = rows_max;
+    a.counts = d_counts;
+    a.n_prev_uniform = rows_uniform;
+    a.n_curr_uniform = rows_uniform;
     a.pairs = d_pairs;
     a.ratio = ratio;
     a.best = d_best;
