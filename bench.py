@@ -1,0 +1,432 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X hot path (matching + tracking; triangulation and float
+matching as separate workloads).
+
+  python bench.py --gpus N --steps K --warmup W [--workload framepair|c3|c4|c5]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL).  Rank 0
+prints ONE JSON line.  The default workload is the one BASELINE.json's metric is
+quoted on: per step every rank processes PAIRS frame pairs, each = robust
+matching of two 8192-keypoint ORB frames (2-NN both ways, ratio test,
+cross-check) + pyramidal LK of 5000 points on a 1280x720 pair (21x21 window,
+maxLevel 3); with N > 1 the ranks then all-gather their match lists.  Inputs
+are resident in HBM before the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "matched+tracked features/sec (ms/frame pair @8k kps) at 1/2/4/8 MI355X"
+VALU_PEAK_TLANEOPS = 78.6   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+KPS = 8192
+DESC_BYTES = 32
+LK_POINTS = 5000
+LK_W, LK_H = 1280, 720
+LK_WIN, LK_MAXLEVEL, LK_COUNT, LK_EPS = (21, 21), 3, 30, 0.01
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="framepair", choices=["framepair", "c3", "c4", "c5"])
+    ap.add_argument("--pairs", type=int, default=32, help="frame pairs per rank and step")
+    ap.add_argument("--frames", type=int, default=512, help="c5: frames in the window")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def dist_setup(n_gpus):
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+        local = 0
+    if n_gpus != world and rank == 0:
+        print(f"warning: --gpus {n_gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    return rank, world, local
+
+
+def barrier_sync(world):
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds, world, dev):
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def timed_steps(step, steps, warmup, world, dev, ctx):
+    for _ in range(warmup):
+        step()
+    ctx.set_profiling(True)
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier_sync(world)
+    dt = time.perf_counter() - t0
+    prof = ctx.profile()
+    ctx.set_profiling(False)
+    return max_over_ranks(dt, world, dev), prof
+
+
+def kernel_line(prof, name):
+    ms, n = prof.get(name, (0.0, 0))
+    return {"total_ms": round(ms, 4), "launches": n, "avg_us": round(1e3 * ms / n, 3) if n else None}
+
+
+# --------------------------------------------------------------------------- framepair
+def lk_inputs(pairs, seed):
+    """`pairs` distinct 1280x720 image pairs (4 textures x different warps) and point sets."""
+    from sfm_amd import synth
+
+    n_tex = min(4, pairs)
+    rng = np.random.default_rng(seed)
+    prevs, currs, pts = [], [], []
+    texes = [synth.texture(LK_H, LK_W, seed=seed + 17 * i) for i in range(n_tex)]
+    for p in range(pairs):
+        tex = texes[p % n_tex]
+        shift = (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)))
+        ang = float(rng.uniform(-0.5, 0.5))
+        prevs.append(synth.to_u8(tex))
+        currs.append(synth.to_u8(synth.affine_warp(tex, shift, ang)))
+        pts.append(synth.grid_points(LK_H, LK_W, LK_POINTS, seed=seed + p, margin=15))
+    return np.stack(prevs), np.stack(currs), np.stack(pts)
+
+
+def cpu_baseline_framepair(desc, prevs, currs, pts):
+    """The CPU oracle on the same workload, bounded to ~10-20 s: all host threads OpenMP gives
+    this process (OMP_NUM_THREADS), float accumulators (OpenCV's accumulator type)."""
+    from oracle import pyoracle
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    pyoracle.robust_matches(pyoracle.NORM_HAMMING, desc[0][:512], desc[1][:512], 0.5)  # warm-up
+    done, t0 = 0, time.perf_counter()
+    while True:
+        i = done % (len(desc) - 1)
+        pyoracle.robust_matches(pyoracle.NORM_HAMMING, desc[i], desc[i + 1], 0.5, threads=0)
+        j = done % len(prevs)
+        pyoracle.pyrlk(prevs[j], currs[j], pts[j], win=LK_WIN, max_level=LK_MAXLEVEL, crit_type=3,
+                       max_count=LK_COUNT, epsilon=LK_EPS, acc_exact=False, threads=0)
+        done += 1
+        el = time.perf_counter() - t0
+        if (el > 10.0 and done >= 2) or el > 25.0:
+            break
+    feats = done * (2 * KPS + LK_POINTS)
+    return {"value": round(feats / el, 1), "unit": "features/s", "cores": threads, "kind": "port",
+            "sample": f"{done} frame pairs (robust matching 2x{KPS}x{KPS}x{DESC_BYTES}B + LK "
+                      f"{LK_POINTS} pts {LK_W}x{LK_H}) in {el:.1f} s, restatement not OpenCV",
+            "ms_per_frame_pair": round(1e3 * el / done, 2)}
+
+
+def run_framepair(args, rank, world, local):
+    import torch
+
+    from sfm_amd import allpairs, capi, synth
+
+    dev = torch.device("cuda", local)
+    P = args.pairs
+    ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
+    # matching inputs: a chain of P+1 frames, pairs (i, i+1); own chain per rank (weak scaling)
+    desc = synth.descriptor_chain(P + 1, KPS, DESC_BYTES, seed=1234 + rank)
+    pairs = np.stack([np.arange(P), np.arange(P) + 1], 1).astype(np.int32)
+    d_desc = torch.from_numpy(desc).to(dev)
+    d_pairs = torch.from_numpy(pairs).to(dev)
+    cap = KPS
+    d_matches = torch.empty((P, cap, 4), dtype=torch.int32, device=dev)
+    d_mcount = torch.empty(P, dtype=torch.int32, device=dev)
+    # tracking inputs
+    prevs, currs, pts = lk_inputs(P, seed=42 + 1000 * rank)
+    d_prev = torch.from_numpy(prevs).to(dev)
+    d_curr = torch.from_numpy(currs).to(dev)
+    d_pts = torch.from_numpy(pts).to(dev)
+    d_out = torch.empty((P, LK_POINTS, 2), dtype=torch.float32, device=dev)
+    d_status = torch.empty((P, LK_POINTS), dtype=torch.uint8, device=dev)
+    d_err = torch.empty((P, LK_POINTS), dtype=torch.float32, device=dev)
+    ctx.reserve(max(capi.Context.match_pairs_workspace(0, P + 1, KPS, DESC_BYTES, P),
+                    capi.Context.pyrlk_workspace(P, LK_W, LK_H, LK_WIN, LK_MAXLEVEL)))
+
+    def match_fn(_sub):
+        ctx.match_pairs_dev(capi.NORM_HAMMING, d_desc, P + 1, KPS * DESC_BYTES, KPS, None,
+                            DESC_BYTES, d_pairs, P, 0.5, d_matches, cap, d_mcount)
+        if world == 1:
+            return d_mcount, None
+        return d_mcount, allpairs.compact_matches(d_matches, d_mcount)
+
+    global_pairs = np.zeros((P * world, 2), np.int32)  # pair k lives on rank k % world
+    gathered = {}
+
+    def step():
+        if world == 1:
+            match_fn(None)
+        else:
+            c, off, m = allpairs.match_all_pairs(global_pairs, match_fn, rank, world)
+            gathered["n"] = int(off[-1])
+        ctx.pyrlk_batch_dev(d_prev, d_curr, P, LK_W * LK_H, LK_W, LK_H, LK_W, d_pts, LK_POINTS,
+                            LK_WIN, LK_MAXLEVEL, 3, LK_COUNT, LK_EPS, 1e-4, 10.0, d_out, d_status,
+                            d_err)
+
+    dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, ctx)
+    feats_step = world * P * (2 * KPS + LK_POINTS)
+    value = feats_step * args.steps / dt
+    matched = int(d_mcount.sum().item())
+    tracked = int(d_status.sum().item())
+
+    # roofline of the dominant kernel (by summed device time over the timed region)
+    dominant = max(prof.items(), key=lambda kv: kv[1][0])[0]
+    ham_ms, ham_n = prof.get("hamming_knn2_kernel", (0.0, 0))
+    lk_ms, lk_n = prof.get("lk_track_kernel", (0.0, 0))
+    ham_ops = 2.0 * P * KPS * KPS * 2 * ((DESC_BYTES + 3) // 4)  # lane-ops per launch
+    roof_ham = {"kernel": "hamming_knn2_kernel", "bound": "valu",
+                "achieved": round(ham_ops / (ham_ms / ham_n * 1e-3) / 1e12, 3) if ham_n else None,
+                "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+                "avg_launch_us": round(1e3 * ham_ms / ham_n, 2) if ham_n else None,
+                "algorithmic_per_launch": f"{ham_ops:.4g} lane-ops = 2 dirs x {P} pairs x "
+                                          f"{KPS}^2 x 16",
+                "traffic": None}
+    roof_ham["frac"] = round(roof_ham["achieved"] / VALU_PEAK_TLANEOPS, 4) if ham_n else None
+    out = {
+        "metric": METRIC, "value": round(value, 1), "unit": "features/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": f"framepair: {P} frame pairs/rank/step; robust matching ORB "
+                               f"{KPS} kps x {DESC_BYTES} B (2-NN both ways, ratio 0.5, "
+                               f"cross-check) + pyrLK {LK_POINTS} pts {LK_W}x{LK_H} win 21x21 "
+                               f"maxLevel {LK_MAXLEVEL} (levels 0..3) crit COUNT+EPS(30,0.01)",
+                   "pairs_per_rank_step": P, "sharding": "by frame pair, all-gather of match lists"
+                   if world > 1 else "single GPU"},
+        "ms_per_frame_pair": round(1e3 * dt / args.steps / P, 4),
+        "dominant_kernel": dominant,
+        "roofline": roof_ham,
+        "kernels": {k: kernel_line(prof, k) for k in sorted(prof)},
+        "check": {"cross_checked_matches_per_step": matched, "tracked_per_step": tracked,
+                  "gathered_matches": gathered.get("n")},
+    }
+    if lk_n:
+        out["lk_track"] = {"avg_launch_us": round(1e3 * lk_ms / lk_n, 2),
+                           "points_per_s": round(P * LK_POINTS / (lk_ms / lk_n * 1e-3), 1)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_framepair(desc, prevs, currs, pts)
+        out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+    ctx.close()
+    return out
+
+
+# --------------------------------------------------------------------------- c3 triangulation
+def run_c3(args, rank, world, local):
+    import torch
+
+    from sfm_amd import capi, synth
+
+    dev = torch.device("cuda", local)
+    n = 10_000_000
+    ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
+    s = synth.triangulation_set(n, seed=7 + rank)
+    d_p1 = torch.from_numpy(s["p1"]).to(dev)
+    d_p2 = torch.from_numpy(s["p2"]).to(dev)
+    d_X = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    d_mask = torch.empty(n, dtype=torch.uint8, device=dev)
+
+    def step():
+        ctx.triangulate_dev(s["K"], s["prev_pose"], s["curr_pose"], s["R"], s["t"], d_p1, d_p2, n,
+                            None, 0, 0, 0, 1e-4, 250.0, 3.0, d_X, None, d_mask, None)
+
+    dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, ctx)
+    ms, cnt = prof["triangulate_dlt_kernel"]
+    avg_s = ms / cnt * 1e-3
+    out = {
+        "metric": "triangulated correspondences/sec (BASELINE config 3)",
+        "value": round(world * n * args.steps / dt, 1), "unit": "correspondences/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "c3: DLT triangulation + reprojection filter, 10M correspondences"},
+        "roofline": {"kernel": "triangulate_dlt_kernel", "bound": "hbm",
+                     "achieved": round(41.0 * n / avg_s / 1e9, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(41.0 * n / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+                     "avg_launch_us": round(avg_s * 1e6, 2), "traffic": None,
+                     "algorithmic_per_launch": "41 B x 1e7 correspondences = 410 MB"},
+        "check": {"mask_true_fraction": round(float(d_mask.float().mean().item()), 4)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle
+
+        m = 200_000
+        t0 = time.perf_counter()
+        pyoracle.triangulate(s["K"], s["prev_pose"], s["curr_pose"], s["R"], s["t"], s["p1"][:m],
+                             s["p2"][:m], threads=1)
+        t1 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 8.0:
+            pyoracle.triangulate(s["K"], s["prev_pose"], s["curr_pose"], s["R"], s["t"],
+                                 s["p1"][:m * 5], s["p2"][:m * 5], threads=0)
+            reps += 1
+        tall = (time.perf_counter() - t0) / reps
+        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+        out["cpu_baseline"] = {"value": round(m * 5 / tall, 1), "unit": "correspondences/s",
+                               "cores": threads, "kind": "port",
+                               "sample": f"{m * 5} correspondences x {reps} passes, all threads; "
+                                         f"1 thread: {m / t1:.0f}/s on {m}",
+                               "one_thread_value": round(m / t1, 1)}
+    ctx.close()
+    return out
+
+
+# --------------------------------------------------------------------------- c4 float matching
+def run_c4(args, rank, world, local):
+    import torch
+
+    from sfm_amd import capi, synth
+
+    dev = torch.device("cuda", local)
+    nq = nt = 20000
+    dim = 128
+    ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
+    res = {}
+    for name, integer in (("sift_like_integer", True), ("unit_norm_real", False)):
+        q, t = synth.float_descriptors(nq, nt, dim=dim, seed=99 + rank, integer=integer)
+        d_q = torch.from_numpy(q).to(dev)
+        d_t = torch.from_numpy(t).to(dev)
+        d_idx = torch.empty((nq, 2), dtype=torch.int32, device=dev)
+        d_dist = torch.empty((nq, 2), dtype=torch.float32, device=dev)
+
+        def step():
+            ctx.knn2_dev(capi.NORM_L2, d_q, nq, dim * 4, d_t, nt, dim * 4, dim, d_idx, d_dist)
+
+        dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, ctx)
+        ms, cnt = prof["l2_candidates_kernel"]
+        avg_s = ms / cnt * 1e-3
+        flop = 2.0 * nq * nt * dim
+        res[name] = {"ms_per_step": round(1e3 * dt / args.steps, 4),
+                     "kernels": {k: kernel_line(prof, k) for k in sorted(prof)},
+                     "roofline": {"kernel": "l2_candidates_kernel", "bound": "mfma",
+                                  "achieved": round(flop / avg_s / 1e12, 2),
+                                  "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(flop / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                  "avg_launch_us": round(avg_s * 1e6, 2), "traffic": None,
+                                  "algorithmic_per_launch": f"2 x {nq} x {nt} x {dim} = {flop:.4g} FLOP"}}
+        res[name]["_dt"] = dt
+    main = res["unit_norm_real"]
+    out = {
+        "metric": "float-descriptor 2-NN query rows/sec (BASELINE config 4)",
+        "value": round(world * nq * args.steps / main["_dt"], 1), "unit": "query rows/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": main["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "c4: L2 2-NN 20000 x 20000 x 128 f32 (unit-norm real-valued; the "
+                               "integer-valued variant is under 'variants')"},
+        "roofline": main["roofline"],
+        "variants": {k: {kk: vv for kk, vv in v.items() if kk != "_dt"} for k, v in res.items()},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle
+
+        q, t = synth.float_descriptors(2000, nt, dim=dim, seed=99, integer=False)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 8.0:
+            pyoracle.knn2_l2(q, t, squared=False, threads=0)
+            reps += 1
+        el = (time.perf_counter() - t0) / reps
+        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+        out["cpu_baseline"] = {"value": round(2000 / el, 1), "unit": "query rows/s",
+                               "cores": threads, "kind": "port",
+                               "sample": f"2000 query rows x {nt} train rows x {reps} passes"}
+    ctx.close()
+    return out
+
+
+# --------------------------------------------------------------------------- c5 all pairs
+def run_c5(args, rank, world, local):
+    import torch
+
+    from sfm_amd import allpairs, capi, synth
+
+    dev = torch.device("cuda", local)
+    F = args.frames
+    ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
+    desc = synth.descriptor_chain(F, KPS, DESC_BYTES, seed=1234)  # replicated on every rank
+    d_desc = torch.from_numpy(desc).to(dev)
+    pairs = allpairs.window_pairs(F)
+    matcher = allpairs.HipPairMatcher(ctx, capi.NORM_HAMMING, d_desc, KPS, DESC_BYTES, 0.5)
+    n_local = len(allpairs.shard_indices(len(pairs), rank, world))
+    ctx.reserve(capi.Context.match_pairs_workspace(0, F, KPS, DESC_BYTES, n_local))
+    result = {}
+
+    def step():
+        c, off, m = allpairs.match_all_pairs(pairs, matcher, rank, world)
+        result["n"] = int(off[-1])
+
+    dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, ctx)
+    ms, cnt = prof["hamming_knn2_kernel"]
+    ops = 2.0 * n_local * KPS * KPS * 16
+    out = {
+        "metric": METRIC, "value": round(len(pairs) * 2 * KPS * args.steps / dt, 1),
+        "unit": "features/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"c5: all {len(pairs)} pairs of a {F}-frame window, {KPS} kps x "
+                               f"{DESC_BYTES} B, round-robin by pair over ranks, all-gather of "
+                               f"match lists"},
+        "ms_per_frame_pair": round(1e3 * dt / args.steps / len(pairs), 5),
+        "roofline": {"kernel": "hamming_knn2_kernel", "bound": "valu",
+                     "achieved": round(ops * args.steps / (ms * 1e-3) / 1e12, 3),
+                     "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "traffic": None},
+        "kernels": {k: kernel_line(prof, k) for k in sorted(prof)},
+        "check": {"gathered_matches": result.get("n")},
+    }
+    out["roofline"]["frac"] = round(out["roofline"]["achieved"] / VALU_PEAK_TLANEOPS, 4)
+    ctx.close()
+    return out
+
+
+def main():
+    args = parse()
+    rank, world, local = dist_setup(args.gpus)
+    run = {"framepair": run_framepair, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.workload]
+    out = run(args, rank, world, local)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,17 @@ const char* sfm_last_error(const sfm_ctx* ctx);
 /* "sfm_hip <version> gfx950" */
 const char* sfm_version(void);
 
+/* ---- measurement aid (no counterpart in the reference) -------------------
+ * With profiling on, every kernel launch of this context is bracketed by HIP
+ * events on the context's stream.  sfm_ctx_profile_read synchronises the
+ * stream and returns the summed duration and the launch count of one kernel
+ * family (ids 0 .. sfm_profile_kernel_count()-1) since profiling was last
+ * switched (switching on or off clears the record). */
+int sfm_ctx_set_profiling(sfm_ctx* ctx, int enabled);
+int sfm_profile_kernel_count(void);
+const char* sfm_profile_kernel_name(int kernel_id);
+int sfm_ctx_profile_read(sfm_ctx* ctx, int kernel_id, double* total_ms, int* launches);
+
 /* ---- descriptor matching ------------------------------------------------ */
 
 /* Brute-force 2-nearest-neighbour search: replaces

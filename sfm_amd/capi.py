@@ -28,6 +28,8 @@ DMATCH_DTYPE = np.dtype(
 EXPORTS = [
     "sfm_ctx_create", "sfm_ctx_create_on_stream", "sfm_ctx_destroy", "sfm_ctx_synchronize",
     "sfm_ctx_reserve", "sfm_last_error", "sfm_version",
+    "sfm_ctx_set_profiling", "sfm_profile_kernel_count", "sfm_profile_kernel_name",
+    "sfm_ctx_profile_read",
     "sfm_knn2", "sfm_knn2_dev", "sfm_ratio_matches", "sfm_robust_matches",
     "sfm_match_pairs_dev", "sfm_match_pairs_workspace",
     "sfm_pyrlk", "sfm_pyrlk_batch_dev", "sfm_pyrlk_workspace",
@@ -54,6 +56,7 @@ def lib():
         l.sfm_last_error.restype = C.c_char_p
         l.sfm_last_error.argtypes = [C.c_void_p]
         l.sfm_version.restype = C.c_char_p
+        l.sfm_profile_kernel_name.restype = C.c_char_p
         l.sfm_ctx_destroy.restype = None
         l.sfm_ctx_destroy.argtypes = [C.c_void_p]
         for name in ("sfm_match_pairs_workspace", "sfm_pyrlk_workspace"):
@@ -109,6 +112,20 @@ class Context:
 
     def reserve(self, nbytes):
         self.check(lib().sfm_ctx_reserve(self._h, C.c_size_t(nbytes)))
+
+    # ---- per-kernel event timing -------------------------------------------
+    def set_profiling(self, enabled):
+        self.check(lib().sfm_ctx_set_profiling(self._h, C.c_int(1 if enabled else 0)))
+
+    def profile(self):
+        """{kernel name: (total ms, launches)} since profiling was switched on."""
+        out = {}
+        for k in range(lib().sfm_profile_kernel_count()):
+            ms, n = C.c_double(0), C.c_int(0)
+            self.check(lib().sfm_ctx_profile_read(self._h, C.c_int(k), C.byref(ms), C.byref(n)))
+            if n.value:
+                out[lib().sfm_profile_kernel_name(C.c_int(k)).decode()] = (ms.value, n.value)
+        return out
 
     # ---- matching ---------------------------------------------------------
     @staticmethod

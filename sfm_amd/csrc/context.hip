@@ -41,6 +41,30 @@ static int grow(sfm_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
     return SFM_OK;
 }
 
+static hipEvent_t take_event(sfm_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+KernelTimer::KernelTimer(sfm_ctx* c, int k) : ctx(c), kid(k) {
+    if (!ctx->profiling) return;
+    start = take_event(ctx);
+    stop = take_event(ctx);
+    if (start && stop) (void)hipEventRecord(start, ctx->stream);
+}
+
+KernelTimer::~KernelTimer() {
+    if (!start || !stop) return;
+    (void)hipEventRecord(stop, ctx->stream);
+    ctx->timed.push_back({kid, start, stop});
+}
+
 int workspace(sfm_ctx* ctx, size_t bytes, void** out) {
     SFM_RETURN_IF(grow(ctx, &ctx->ws, &ctx->ws_bytes, bytes));
     *out = ctx->ws;
@@ -102,6 +126,11 @@ void sfm_ctx_destroy(sfm_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto& t : ctx->timed) {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->staging) (void)hipFree(ctx->staging);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -125,5 +154,47 @@ const char* sfm_last_error(const sfm_ctx* ctx) {
 }
 
 const char* sfm_version(void) { return "sfm_hip 0.1 gfx950"; }
+
+int sfm_ctx_set_profiling(sfm_ctx* ctx, int enabled) {
+    if (!ctx) return sfm::set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& t : ctx->timed) {
+        ctx->event_pool.push_back(t.start);
+        ctx->event_pool.push_back(t.stop);
+    }
+    ctx->timed.clear();
+    ctx->profiling = enabled != 0;
+    return SFM_OK;
+}
+
+int sfm_profile_kernel_count(void) { return sfm::KID_COUNT; }
+
+const char* sfm_profile_kernel_name(int kernel_id) {
+    static const char* names[sfm::KID_COUNT] = {
+        "hamming_knn2_kernel", "ratio_cross_kernel", "knn_finalize_kernel", "pack_rows_kernel",
+        "ratio_compact_kernel", "l2_candidates_kernel", "l2_rescore_kernel", "l2_pack_kernel",
+        "lk_pad_level0_kernel", "lk_pyr_down_kernel", "lk_scharr_kernel", "lk_track_kernel",
+        "triangulate_dlt_kernel"};
+    return kernel_id >= 0 && kernel_id < sfm::KID_COUNT ? names[kernel_id] : "";
+}
+
+int sfm_ctx_profile_read(sfm_ctx* ctx, int kernel_id, double* total_ms, int* launches) {
+    if (!ctx) return sfm::set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (kernel_id < 0 || kernel_id >= sfm::KID_COUNT || !total_ms || !launches)
+        return sfm::set_error(ctx, SFM_E_INVALID, "bad profile query");
+    SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    double sum = 0;
+    int n = 0;
+    for (auto& t : ctx->timed)
+        if (t.kid == kernel_id) {
+            float ms = 0.f;
+            SFM_HIP_CHECK(ctx, hipEventElapsedTime(&ms, t.start, t.stop));
+            sum += ms;
+            ++n;
+        }
+    *total_ms = sum;
+    *launches = n;
+    return SFM_OK;
+}
 
 }  // extern "C"

@@ -218,6 +218,7 @@ __global__ void knn_finalize_kernel(const uint2* __restrict__ keys, int splits, 
 
 template <int W, int Q>
 int launch_t(sfm_ctx* ctx, const KnnArgs& a, int grid) {
+    KernelTimer timer(ctx, KID_HAMMING_KNN2);
     hipLaunchKernelGGL((hamming_knn2_kernel<W, Q>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
@@ -274,6 +275,7 @@ int pack_rows(sfm_ctx* ctx, const void* d_src, int n, size_t src_stride, int d_b
     const size_t total = (size_t)n * row_words;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
+    KernelTimer timer(ctx, KID_PACK_ROWS);
     hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream,
                        static_cast<const uint8_t*>(d_src), n, src_stride, d_bytes,
                        static_cast<uint32_t*>(d_dst), row_words);
@@ -318,6 +320,7 @@ int launch_knn_finalize(sfm_ctx* ctx, const KnnPlan& plan, const uint32_t* d_key
                         int32_t* d_idx, float* d_dist) {
     (void)nt;
     if (nq <= 0) return SFM_OK;
+    KernelTimer timer(ctx, KID_KNN_FINALIZE);
     hipLaunchKernelGGL(knn_finalize_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream,
                        reinterpret_cast<const uint2*>(d_keys), plan.splits, plan.rows_max, nq,
                        d_idx, d_dist);

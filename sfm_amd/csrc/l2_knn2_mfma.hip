@@ -358,6 +358,7 @@ int make_l2_plan(const sfm_ctx* ctx, int dim, int nq_max, int nt_max, int n_prob
 
 template <int K, int NT>
 int launch_candidates(sfm_ctx* ctx, const L2Args& a, long grid) {
+    KernelTimer timer(ctx, KID_L2_CANDIDATES);
     hipLaunchKernelGGL((l2_candidates_kernel<K, NT>), dim3((unsigned)grid), dim3(kBlock), 0,
                        ctx->stream, a);
     SFM_HIP_CHECK(ctx, hipGetLastError());
@@ -412,6 +413,7 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     r.knn_dist = knn_dist;
     const int nq_max = d_counts ? rows_cap : nq_uniform;
     const dim3 rgrid((nq_max + kBlock / 64 - 1) / (kBlock / 64), n_problems);
+    KernelTimer timer(ctx, KID_L2_RESCORE);
     hipLaunchKernelGGL(l2_rescore_kernel, rgrid, dim3(kBlock), 0, ctx->stream, r);
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
@@ -420,6 +422,7 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
 int l2_pack(sfm_ctx* ctx, const void* src, int n, size_t stride_bytes, int dim, float* dst, int K,
             float* norms) {
     if (n <= 0) return SFM_OK;
+    KernelTimer timer(ctx, KID_L2_PACK);
     hipLaunchKernelGGL(l2_pack_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream,
                        static_cast<const uint8_t*>(src), n, stride_bytes, dim, dst, K, norms);
     SFM_HIP_CHECK(ctx, hipGetLastError());

@@ -550,6 +550,7 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     {
         const int S = g.stride[0];
         const dim3 grid((S / 4 + 255) / 256, g.h[0] + 2 * g.bh, 2 * n_pairs);
+        KernelTimer timer(ctx, KID_LK_PAD_LEVEL0);
         hipLaunchKernelGGL(lk_pad_level0_kernel, grid, blk, 0, ctx->stream, d_prev, d_curr,
                            image_stride, stride, g, bufs.pyr_prev, bufs.pyr_curr);
         SFM_HIP_CHECK(ctx, hipGetLastError());
@@ -557,6 +558,7 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     for (int l = 1; l <= g.levels; ++l) {
         const int S = g.stride[l];
         const dim3 grid((S / 4 + 255) / 256, g.h[l] + 2 * g.bh, 2 * n_pairs);
+        KernelTimer timer(ctx, KID_LK_PYR_DOWN);
         hipLaunchKernelGGL(lk_pyr_down_kernel, grid, blk, 0, ctx->stream, g, l, bufs.pyr_prev,
                            bufs.pyr_curr);
         SFM_HIP_CHECK(ctx, hipGetLastError());
@@ -564,6 +566,7 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     for (int l = 0; l <= g.levels; ++l) {
         const int S = g.stride[l];
         const dim3 grid((S + 255) / 256, g.h[l] + 2 * g.bh, n_pairs);
+        KernelTimer timer(ctx, KID_LK_SCHARR);
         hipLaunchKernelGGL(lk_scharr_kernel, grid, blk, 0, ctx->stream, g, l, bufs.pyr_prev,
                            bufs.deriv);
         SFM_HIP_CHECK(ctx, hipGetLastError());
@@ -589,6 +592,7 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     a.err = d_err;
     const int spl = (a.slots + 63) / 64;
     const dim3 grid((a.n_total + 3) / 4);
+    KernelTimer timer(ctx, KID_LK_TRACK);
     switch (spl) {
         case 1: hipLaunchKernelGGL(lk_track_kernel<1>, grid, blk, 0, ctx->stream, a); break;
         case 2: hipLaunchKernelGGL(lk_track_kernel<2>, grid, blk, 0, ctx->stream, a); break;

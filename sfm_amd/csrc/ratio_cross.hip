@@ -193,6 +193,7 @@ int launch_ratio_cross(sfm_ctx* ctx, const KnnPlan& plan, const uint32_t* d_keys
     a.matches = d_matches;
     a.cap = cap;
     a.match_counts = d_match_counts;
+    KernelTimer timer(ctx, KID_RATIO_CROSS);
     hipLaunchKernelGGL(ratio_cross_kernel, dim3(n_pairs), dim3(kThreads), 0, ctx->stream, a);
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
@@ -220,6 +221,7 @@ int launch_ratio_cross_knn(sfm_ctx* ctx, const int32_t* d_knn_idx, const float* 
     a.matches = d_matches;
     a.cap = cap;
     a.match_counts = d_match_counts;
+    KernelTimer timer(ctx, KID_RATIO_CROSS);
     hipLaunchKernelGGL(ratio_cross_kernel, dim3(n_pairs), dim3(kThreads), 0, ctx->stream, a);
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
@@ -227,6 +229,7 @@ int launch_ratio_cross_knn(sfm_ctx* ctx, const int32_t* d_knn_idx, const float* 
 
 int launch_ratio_compact(sfm_ctx* ctx, const int32_t* d_idx, const float* d_dist, int nq, int nt,
                          float ratio, sfm_dmatch* d_out, int32_t* d_count) {
+    KernelTimer timer(ctx, KID_RATIO_COMPACT);
     hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, d_idx,
                        d_dist, nq, nt, ratio, d_out, d_count);
     SFM_HIP_CHECK(ctx, hipGetLastError());

@@ -7,8 +7,33 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "sfm_hip.h"
+
+namespace sfm {
+// Kernel families, for the optional per-kernel event timing (sfm_ctx_set_profiling).
+enum KernelId {
+    KID_HAMMING_KNN2 = 0,
+    KID_RATIO_CROSS,
+    KID_KNN_FINALIZE,
+    KID_PACK_ROWS,
+    KID_RATIO_COMPACT,
+    KID_L2_CANDIDATES,
+    KID_L2_RESCORE,
+    KID_L2_PACK,
+    KID_LK_PAD_LEVEL0,
+    KID_LK_PYR_DOWN,
+    KID_LK_SCHARR,
+    KID_LK_TRACK,
+    KID_TRIANGULATE_DLT,
+    KID_COUNT
+};
+struct TimedLaunch {
+    int kid;
+    hipEvent_t start, stop;
+};
+}  // namespace sfm
 
 struct sfm_ctx {
     int device = 0;
@@ -20,6 +45,9 @@ struct sfm_ctx {
     size_t staging_bytes = 0;
     int num_cus = 256;
     std::string err;
+    bool profiling = false;
+    std::vector<sfm::TimedLaunch> timed;      // launches recorded since the last reset
+    std::vector<hipEvent_t> event_pool;       // events free for reuse
 };
 
 namespace sfm {
@@ -39,6 +67,15 @@ int set_error(sfm_ctx* ctx, int code, const char* fmt, ...);
         int _rc = (expr);          \
         if (_rc != SFM_OK) return _rc; \
     } while (0)
+
+// Brackets one kernel launch with HIP events on the context's stream when profiling is on.
+struct KernelTimer {
+    sfm_ctx* ctx;
+    int kid;
+    hipEvent_t start = nullptr, stop = nullptr;
+    KernelTimer(sfm_ctx* c, int k);
+    ~KernelTimer();
+};
 
 // Device workspace of at least `bytes`; contents are not preserved on growth.
 int workspace(sfm_ctx* ctx, size_t bytes, void** out);

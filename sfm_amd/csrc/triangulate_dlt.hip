@@ -249,6 +249,7 @@ int sfm_triangulate_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
     a.rgb = d_rgb;
     a.mask = d_mask;
     a.err = d_err;
+    KernelTimer timer(ctx, KID_TRIANGULATE_DLT);
     hipLaunchKernelGGL(triangulate_dlt_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;

@@ -1,0 +1,165 @@
+"""CPU-only tests: the C-ABI library loads and exports what include/sfm_hip.h
+declares, the product path fails loudly without a GPU, host-side logic, and the
+multi-rank gather over gloo (world size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sfm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sfm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sfm_amd import capi
+
+    lib = capi.lib()
+    names = _declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/sfm_hip.h but not exported"
+    assert sorted(capi.EXPORTS) == names
+    assert b"gfx950" in lib.sfm_version()
+
+
+def test_dmatch_layout_matches_cv_dmatch():
+    from sfm_amd import capi
+
+    assert capi.DMATCH_DTYPE.itemsize == 16
+    assert [capi.DMATCH_DTYPE.fields[k][1] for k in ("queryIdx", "trainIdx", "imgIdx", "distance")] \
+        == [0, 4, 8, 12]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a machine without a GPU")
+def test_no_gpu_fails_loudly():
+    """There is no CPU fallback: creating a context without a device raises."""
+    from sfm_amd import capi
+
+    with pytest.raises(capi.SfmError) as e:
+        capi.Context(0)
+    assert "device" in str(e.value).lower() or "hip" in str(e.value).lower()
+    import sfm_amd
+    m = sfm_amd.DescriptorMatcher("BRUTEFORCE_HAMMING", 0.5)
+    with pytest.raises(capi.SfmError):
+        m.ratioMaches(np.zeros((4, 32), np.uint8), np.zeros((4, 32), np.uint8))
+
+
+def test_package_does_not_import_the_oracle():
+    """The product path must not route through oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sfm_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in text and "liboracle" not in text and "orc_" not in text, f
+
+
+def test_matcher_constructor_mapping():
+    import sfm_amd
+    from sfm_amd import capi
+
+    assert sfm_amd.DescriptorMatcher("bruteforce_hamming", 0.5).norm == capi.NORM_HAMMING
+    assert sfm_amd.DescriptorMatcher("BRUTEFORCE_SL2", 0.5).norm == capi.NORM_L2SQR
+    assert sfm_amd.DescriptorMatcher("BRUTEFORCE", 0.5).norm == capi.NORM_L2
+    assert sfm_amd.DescriptorMatcher("akaze?", 0.5).norm == capi.NORM_L2
+    with pytest.raises(capi.SfmError):
+        sfm_amd.DescriptorMatcher("flannbased", 0.5)
+    of = sfm_amd.OptFlow((3, 250, 0.0), 30, 5, 10.0, 300, 0.01, 20.0, 100)
+    assert of.winSize == (30, 30) and of.additionalSettings.maxError == 10.0
+    cam = sfm_amd.CameraParameters(np.diag([2000.0, 2000.0, 2.0]), None, 2.0)
+    assert cam.K33d[2, 2] == 1.0 and cam.K33d[0, 0] == 1000.0
+
+
+def test_window_pairs_and_sharding():
+    from sfm_amd import allpairs
+
+    p = allpairs.window_pairs(512)
+    assert len(p) == 130816 and tuple(p[0]) == (0, 1) and tuple(p[-1]) == (510, 511)
+    assert len(allpairs.window_pairs(10, window=2)) == 9 + 8
+    for world in (1, 2, 3, 8):
+        got = np.sort(np.concatenate([allpairs.shard_indices(len(p), r, world)
+                                      for r in range(world)]))
+        np.testing.assert_array_equal(got, np.arange(len(p)))
+        sizes = [len(allpairs.shard_indices(len(p), r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_synthetic_inputs_are_seeded():
+    from sfm_amd import synth
+
+    a = synth.descriptor_chain(3, 64, 32, seed=5)
+    b = synth.descriptor_chain(3, 64, 32, seed=5)
+    np.testing.assert_array_equal(a, b)
+    assert a.shape == (3, 64, 32) and a.dtype == np.uint8
+    pts = synth.grid_points(720, 1280, 5000)
+    assert pts.shape == (5000, 2) and pts[:, 0].min() >= 15 and pts[:, 1].max() <= 720 - 16
+    s = synth.triangulation_set(100)
+    assert s["p1"].dtype == np.float32 and s["p1"].shape == (100, 2)
+
+
+_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from sfm_amd import allpairs, synth
+from oracle import pyoracle   # the checker stands in for the GPU matcher in this CPU test
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+desc = synth.descriptor_chain(7, 300, 32, seed=11)
+counts = np.array([300, 280, 300, 1, 300, 255, 300])
+pairs = allpairs.window_pairs(7)
+
+def match_fn(sub):
+    cs, ms = [], []
+    for a, b in sub:
+        m = pyoracle.robust_matches(pyoracle.NORM_HAMMING, desc[a][:counts[a]], desc[b][:counts[b]], 0.8)
+        cs.append(len(m))
+        ms.append(np.stack([m["queryIdx"], m["trainIdx"], m["distance"].view(np.int32)], 1).reshape(-1, 3))
+    c = torch.tensor(cs, dtype=torch.int32)
+    p = torch.from_numpy(np.concatenate(ms).astype(np.int32)) if ms else torch.empty((0, 3), dtype=torch.int32)
+    return c, p
+
+c, off, m = allpairs.match_all_pairs(pairs, match_fn, rank, world)
+np.savez(os.path.join({out!r}, f"rank{{rank}}.npz"), c=c, off=off, m=m.numpy())
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_all_pairs_gather_gloo_world2(tmp_path, oracle):
+    from sfm_amd import allpairs, synth
+
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2",
+               OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    # single-process truth
+    desc = synth.descriptor_chain(7, 300, 32, seed=11)
+    counts = np.array([300, 280, 300, 1, 300, 255, 300])
+    pairs = allpairs.window_pairs(7)
+    want_c, want_m = [], []
+    for a, b in pairs:
+        m = oracle.robust_matches(oracle.NORM_HAMMING, desc[a][:counts[a]], desc[b][:counts[b]], 0.8)
+        want_c.append(len(m))
+        want_m.append(np.stack([m["queryIdx"], m["trainIdx"], m["distance"].view(np.int32)], 1))
+    want_m = np.concatenate(want_m).astype(np.int32)
+    assert sum(want_c) > 300 and 0 in want_c
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        np.testing.assert_array_equal(got["c"], np.array(want_c))
+        np.testing.assert_array_equal(got["off"], np.concatenate([[0], np.cumsum(want_c)]))
+        np.testing.assert_array_equal(got["m"], want_m)
