@@ -17,6 +17,8 @@
 // The train dimension can be split over workgroups (to fill the chip when there
 // are few query tiles); each split writes its two best keys per query and a
 // second kernel merges them.
+#include <cstdlib>
+
 #include "sfm_internal.h"
 
 namespace sfm {
@@ -259,7 +261,12 @@ KnnPlan make_knn_plan(const sfm_ctx* ctx, int norm, int d, int nq_max, int nt_ma
     // Split the train rows until the launch has about 8 workgroups per CU, but
     // keep at least two tiles of train rows per split.
     const int tile_rows = kTileBytes / (p.row_words * 4);
-    const long want = 8L * ctx->num_cus;
+    static const int per_cu = [] {
+        const char* e = getenv("SFM_KNN_BLOCKS_PER_CU");  // tuning knob
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 8;
+    }();
+    const long want = (long)per_cu * ctx->num_cus;
     long blocks = (long)qtiles * n_problems;
     int splits = (int)((want + blocks - 1) / blocks);
     const int max_splits = (nt_max + 2 * tile_rows - 1) / (2 * tile_rows);

@@ -56,7 +56,8 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // ---- pyramid construction ---------------------------------------------------
 
 // Level 0 of both images of every pair: copy with a reflect-101 border.
-// grid.z = 2*n_pairs (even: previous image, odd: next image).
+// grid.z = 2*n_pairs (even: previous image, odd: next image).  One thread writes
+// 16 bytes; in the interior that is one unaligned 16-byte load and one store.
 __global__ void lk_pad_level0_kernel(const uint8_t* __restrict__ prev,
                                      const uint8_t* __restrict__ curr, size_t image_stride,
                                      size_t row_stride, LkGeom g, uint8_t* __restrict__ pyr_prev,
@@ -65,24 +66,47 @@ __global__ void lk_pad_level0_kernel(const uint8_t* __restrict__ prev,
     const uint8_t* src = (which ? curr : prev) + (size_t)pair * image_stride;
     uint8_t* dst = (which ? pyr_curr : pyr_prev) + (size_t)pair * g.block + g.img_off[0];
     const int S = g.stride[0], w = g.w[0], h = g.h[0];
-    const int y = (int)blockIdx.y - g.bh;
-    if (y >= h + g.bh) return;
-    const int sy = reflect101(y, h);
-    const uint8_t* srow = src + (size_t)sy * row_stride;
-    uint8_t* drow = dst + (ptrdiff_t)y * S - g.bw;
-    for (int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4; x4 < S; x4 += gridDim.x * blockDim.x * 4) {
-        uint32_t v = 0;
+    const int per_row = S / 16, total = per_row * (h + 2 * g.bh);
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int y = t / per_row - g.bh, x16 = (t % per_row) * 16;
+        const int sy = reflect101(y, h);
+        const uint8_t* srow = src + (size_t)sy * row_stride;
+        uint8_t* drow = dst + (ptrdiff_t)y * S - g.bw;
+        const int x = x16 - g.bw;
+        uint4 v;
+        if (x >= 0 && x + 16 <= w) {
+            __builtin_memcpy(&v, srow + x, 16);
+        } else {
+            uint32_t q[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int x = x4 + b - g.bw;
-            const uint32_t px = x < w + g.bw ? srow[reflect101(x, w)] : 0u;
-            v |= px << (8 * b);
+            for (int b = 0; b < 16; ++b) {
+                const int xb = x + b;
+                const uint32_t px = xb < w + g.bw ? srow[reflect101(xb, w)] : 0u;
+                q[b >> 2] |= px << (8 * (b & 3));
+            }
+            v = make_uint4(q[0], q[1], q[2], q[3]);
         }
-        *reinterpret_cast<uint32_t*>(drow + x4) = v;
+        *reinterpret_cast<uint4*>(drow + x16) = v;
     }
 }
 
+// pyrDown at output pixel (rx, ry) of a level whose source (with its reflect-101
+// border, which holds exactly the values pyrDown's border handling asks for) is src.
+__device__ __forceinline__ uint32_t pyr_down_px(const uint8_t* src, int SS, int rx, int ry) {
+    const uint8_t* s = src + (ptrdiff_t)(2 * ry - 2) * SS + (2 * rx - 2);
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const uint8_t* r = s + (ptrdiff_t)k * SS;
+        const int hsum = r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4];
+        acc += hsum * (k == 2 ? 6 : (k == 1 || k == 3) ? 4 : 1);
+    }
+    return (uint32_t)((acc + 128) >> 8);
+}
+
 // Level l (>= 1) of both images from level l-1, including its reflect-101 border.
+// One thread writes 4 output pixels; in the interior they share five 16-byte
+// source loads (11 source columns x 5 rows).
 __global__ void lk_pyr_down_kernel(LkGeom g, int level, uint8_t* __restrict__ pyr_prev,
                                    uint8_t* __restrict__ pyr_curr) {
     const int pair = blockIdx.z >> 1, which = blockIdx.z & 1;
@@ -91,30 +115,39 @@ __global__ void lk_pyr_down_kernel(LkGeom g, int level, uint8_t* __restrict__ py
     uint8_t* dst = base + g.img_off[level];
     const int SS = g.stride[level - 1];
     const int S = g.stride[level], w = g.w[level], h = g.h[level];
-    const int y = (int)blockIdx.y - g.bh;
-    if (y >= h + g.bh) return;
-    const int ry = reflect101(y, h);
-    uint8_t* drow = dst + (ptrdiff_t)y * S - g.bw;
-    for (int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4; x4 < S; x4 += gridDim.x * blockDim.x * 4) {
+    const int per_row = S / 4, total = per_row * (h + 2 * g.bh);
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int y = t / per_row - g.bh, x4 = (t % per_row) * 4;
+        const int ry = reflect101(y, h);
+        uint8_t* drow = dst + (ptrdiff_t)y * S - g.bw;
+        const int x = x4 - g.bw;
         uint32_t v = 0;
+        if (x >= 0 && x + 4 <= w) {
+            // source columns 2x-2 .. 2x+8 of rows 2ry-2 .. 2ry+2
+            int col[4] = {0, 0, 0, 0};
+            const uint8_t* s = src + (ptrdiff_t)(2 * ry - 2) * SS + (2 * x - 2);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int x = x4 + b - g.bw;
-            uint32_t px = 0;
-            if (x < w + g.bw) {
-                const int rx = reflect101(x, w);
-                // The source border already holds the reflect-101 values pyrDown asks for.
-                const uint8_t* s = src + (ptrdiff_t)(2 * ry - 2) * SS + (2 * rx - 2);
-                int acc = 0;
+            for (int k = 0; k < 5; ++k) {
+                uint32_t q[4];
+                __builtin_memcpy(q, s + (ptrdiff_t)k * SS, 16);
+                int b[12];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const uint8_t* r = s + (ptrdiff_t)k * SS;
-                    const int hsum = r[2] * 6 + (r[1] + r[3]) * 4 + r[0] + r[4];
-                    acc += hsum * (k == 2 ? 6 : (k == 1 || k == 3) ? 4 : 1);
-                }
-                px = (uint32_t)((acc + 128) >> 8);
+                for (int i = 0; i < 12; ++i) b[i] = (q[i >> 2] >> (8 * (i & 3))) & 0xFF;
+                const int wk = k == 2 ? 6 : (k == 1 || k == 3) ? 4 : 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    col[i] += wk * (b[2 * i + 2] * 6 + (b[2 * i + 1] + b[2 * i + 3]) * 4 + b[2 * i] +
+                                    b[2 * i + 4]);
             }
-            v |= px << (8 * b);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v |= (uint32_t)((col[i] + 128) >> 8) << (8 * i);
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int xb = x + b;
+                const uint32_t px = xb < w + g.bw ? pyr_down_px(src, SS, reflect101(xb, w), ry) : 0u;
+                v |= px << (8 * b);
+            }
         }
         *reinterpret_cast<uint32_t*>(drow + x4) = v;
     }
@@ -171,27 +204,72 @@ struct LkArgs {
     float* err;
 };
 
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+typedef short short2_t __attribute__((ext_vector_type(2)));
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_add(int v) {
     return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
 }
 
-// Sum over the 64 lanes, returned in every lane.
-__device__ __forceinline__ int wave_sum(int v) {
-    v = dpp_add<0x111, 0xF>(v);  // row_shr:1
-    v = dpp_add<0x112, 0xF>(v);  // row_shr:2
-    v = dpp_add<0x114, 0xF>(v);  // row_shr:4
-    v = dpp_add<0x118, 0xF>(v);  // row_shr:8  -> lane 15 of each row holds the row sum
-    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-    return __builtin_amdgcn_readlane(v, 63);
+// N independent wave sums advanced in lock step, so that consecutive DPP adds
+// belong to different chains and need no wait states between them.
+template <int N>
+__device__ __forceinline__ void wave_sum_n(int (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x111, 0xF>(v[i]);  // row_shr:1
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x112, 0xF>(v[i]);  // row_shr:2
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x114, 0xF>(v[i]);  // row_shr:4
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x118, 0xF>(v[i]);  // row_shr:8: lane 15 of a row = row sum
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x142, 0xA>(v[i]);  // row_bcast:15 into rows 1, 3
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x143, 0xC>(v[i]);  // row_bcast:31 into rows 2, 3
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_readlane(v[i], 63);
 }
 
-// Exact sum of per-lane int32 partials whose total may exceed 32 bits.
-__device__ __forceinline__ long long wave_sum_wide(int v) {
-    const int lo = wave_sum(v & 0xFFFF);
-    const int hi = wave_sum(v >> 16);
-    return (long long)hi * 65536 + lo;
+// Exact 64-bit sums of N per-lane int32 partials (|partial| < 2^28).  Eight
+// lanes are added in 32 bits (cannot overflow), then the low 16 bits and the
+// high part are reduced separately.  EARLY = false splits before any add (for
+// partials up to 2^31).
+template <int N, bool EARLY>
+__device__ __forceinline__ void wave_sum_wide_n(const int (&p)[N], long long (&out)[N]) {
+    int v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = p[i];
+    if (EARLY) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = dpp_add<0x111, 0xF>(v[i]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = dpp_add<0x112, 0xF>(v[i]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = dpp_add<0x114, 0xF>(v[i]);  // lanes 7, 15 of a row: 8-lane sums
+    }
+    int h[2 * N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        h[2 * i] = v[i] & 0xFFFF;
+        h[2 * i + 1] = v[i] >> 16;
+    }
+    if (EARLY) {
+        // add the two 8-lane sums of each row (lane 7 into lane 15), then rows
+#pragma unroll
+        for (int i = 0; i < 2 * N; ++i) h[i] = dpp_add<0x118, 0xF>(h[i]);
+#pragma unroll
+        for (int i = 0; i < 2 * N; ++i) h[i] = dpp_add<0x142, 0xA>(h[i]);
+#pragma unroll
+        for (int i = 0; i < 2 * N; ++i) h[i] = dpp_add<0x143, 0xC>(h[i]);
+#pragma unroll
+        for (int i = 0; i < 2 * N; ++i) h[i] = __builtin_amdgcn_readlane(h[i], 63);
+    } else {
+        wave_sum_n<2 * N>(h);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = (long long)h[2 * i + 1] * 65536 + h[2 * i];
 }
 
 __device__ __forceinline__ uint2 load_u8x8(const uint8_t* p) {
@@ -200,34 +278,97 @@ __device__ __forceinline__ uint2 load_u8x8(const uint8_t* p) {
     return v;
 }
 
-__device__ __forceinline__ void unpack8(uint2 v, int (&b)[8]) {
-    b[0] = v.x & 0xFF;
-    b[1] = (v.x >> 8) & 0xFF;
-    b[2] = (v.x >> 16) & 0xFF;
-    b[3] = v.x >> 24;
-    b[4] = v.y & 0xFF;
-    b[5] = (v.y >> 8) & 0xFF;
-    b[6] = (v.y >> 16) & 0xFF;
-    b[7] = v.y >> 24;
+// (b[J] | b[J+1] << 16) out of the eight bytes {v.x, v.y}: the u16 pair of two
+// horizontally adjacent pixels.
+template <int J>
+__device__ __forceinline__ uint32_t px_pair(uint2 v) {
+    constexpr uint32_t sel = (uint32_t)J | (0x0Cu << 8) | ((uint32_t)(J + 1) << 16) | (0x0Cu << 24);
+    return __builtin_amdgcn_perm(v.y, v.x, sel);
 }
 
 struct Weights {
-    int w00, w01, w10, w11;
+    uint32_t w0;  // iw00 | iw01 << 16 (row y)
+    uint32_t w1;  // iw10 | iw11 << 16 (row y + 1)
 };
 
 __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
+    const int w00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
+    const int w01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
+    const int w10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
+    const int w11 = (1 << W_BITS) - w00 - w01 - w10;
     Weights w;
-    w.w00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
-    w.w01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
-    w.w10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
-    w.w11 = (1 << W_BITS) - w.w00 - w.w01 - w.w10;
+    w.w0 = (uint32_t)w00 | ((uint32_t)w01 << 16);
+    w.w1 = (uint32_t)w10 | ((uint32_t)w11 << 16);  // w11 may be negative: it sits in the high half
     return w;
 }
 
-// Interpolated window pixel, 5 fractional bits: CV_DESCALE(..., W_BITS-5).
-__device__ __forceinline__ int interp_px(int p00, int p01, int p10, int p11, const Weights& w) {
-    return (p00 * w.w00 + p01 * w.w01 + p10 * w.w10 + p11 * w.w11 + (1 << (W_BITS - 5 - 1))) >>
-           (W_BITS - 5);
+// Interpolated window pixel with 5 fractional bits, CV_DESCALE(..., W_BITS-5):
+// two 16-bit dot products (row y and row y+1) on pixel pairs and weight pairs.
+// Signed: iw11 = 2^14 - (the three rounded weights) can be -1.
+__device__ __forceinline__ int interp_px(uint32_t pair0, uint32_t pair1, const Weights& w) {
+    int acc = 1 << (W_BITS - 5 - 1);
+    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, pair0),
+                                 __builtin_bit_cast(short2_t, w.w0), acc, false);
+    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, pair1),
+                                 __builtin_bit_cast(short2_t, w.w1), acc, false);
+    return acc >> (W_BITS - 5);
+}
+
+// Interpolated derivative, CV_DESCALE(..., W_BITS), on signed 16-bit pairs.
+__device__ __forceinline__ int interp_deriv(uint32_t pair0, uint32_t pair1, const Weights& w) {
+    int acc = 1 << (W_BITS - 1);
+    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, pair0),
+                                 __builtin_bit_cast(short2_t, w.w0), acc, false);
+    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, pair1),
+                                 __builtin_bit_cast(short2_t, w.w1), acc, false);
+    return acc >> W_BITS;
+}
+
+// (lo16(a) | lo16(b) << 16): two 16-bit values side by side
+__device__ __forceinline__ uint32_t pack16(int a, int b) {
+    return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x05040100u);
+}
+
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), c,
+                                  false);
+}
+
+__device__ __forceinline__ int mad24(int a, int b, int c) {
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
+    const short2_t d = __builtin_bit_cast(short2_t, a) - __builtin_bit_cast(short2_t, b);
+    return __builtin_bit_cast(uint32_t, d);
+}
+
+// One slot's window, 7 pixels as three 16-bit pairs (0,1) (2,3) (4,5) and a single (6).
+struct SlotWin {
+    uint32_t i01, i23, i45;  // interpolated I, 5 fractional bits
+    uint32_t x01, x23, x45;  // interpolated dI/dx (0 outside the window)
+    uint32_t y01, y23, y45;  // interpolated dI/dy
+    int i6, x6, y6;
+    uint32_t m01, m23, m45;  // 0xFFFF per pixel inside the window
+    int m6;
+};
+
+// Interpolated J window of one slot, as three pairs and a single, 5 fractional bits.
+__device__ __forceinline__ void window_interp(const uint8_t* row0, int S, const Weights& wt,
+                                              uint32_t& p01, uint32_t& p23, uint32_t& p45, int& p6) {
+    const uint2 a = load_u8x8(row0), b = load_u8x8(row0 + S);
+    const int s0 = interp_px(px_pair<0>(a), px_pair<0>(b), wt);
+    const int s1 = interp_px(px_pair<1>(a), px_pair<1>(b), wt);
+    const int s2 = interp_px(px_pair<2>(a), px_pair<2>(b), wt);
+    const int s3 = interp_px(px_pair<3>(a), px_pair<3>(b), wt);
+    const int s4 = interp_px(px_pair<4>(a), px_pair<4>(b), wt);
+    const int s5 = interp_px(px_pair<5>(a), px_pair<5>(b), wt);
+    p6 = interp_px(px_pair<6>(a), px_pair<6>(b), wt);
+    p01 = pack16(s0, s1);
+    p23 = pack16(s2, s3);
+    p45 = pack16(s4, s5);
 }
 
 template <int SPL>
@@ -242,7 +383,8 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
     const uint32_t* pyrD = a.deriv + (size_t)pair * g.block;
 
     // slot geometry of this lane
-    int srow[SPL], sx0[SPL], snpx[SPL];
+    int srow[SPL], sx0[SPL];
+    SlotWin win[SPL];
 #pragma unroll
     for (int s = 0; s < SPL; ++s) {
         const int slot = lane + 64 * s;
@@ -250,7 +392,11 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
         const int sl = valid ? slot : 0;
         srow[s] = sl / a.segs;
         sx0[s] = (sl % a.segs) * kPxPerSlot;
-        snpx[s] = valid ? min(kPxPerSlot, a.win_w - sx0[s]) : 0;
+        const int npx = valid ? min(kPxPerSlot, a.win_w - sx0[s]) : 0;
+        win[s].m01 = (npx > 0 ? 0xFFFFu : 0u) | (npx > 1 ? 0xFFFF0000u : 0u);
+        win[s].m23 = (npx > 2 ? 0xFFFFu : 0u) | (npx > 3 ? 0xFFFF0000u : 0u);
+        win[s].m45 = (npx > 4 ? 0xFFFFu : 0u) | (npx > 5 ? 0xFFFF0000u : 0u);
+        win[s].m6 = npx > 6 ? -1 : 0;
     }
 
     const float2 p0 = a.prev_pts[pt];
@@ -260,14 +406,13 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
     int status = 1;
     float err = 0.f;
 
-    int Iw[SPL][kPxPerSlot];       // interpolated I, 5 fractional bits
-    uint32_t dIw[SPL][kPxPerSlot]; // interpolated (Ix | Iy << 16)
-
     for (int level = g.levels; level >= 0; --level) {
         const int lw = g.w[level], lh = g.h[level], S = g.stride[level];
-        const uint8_t* I = pyrI + g.img_off[level];
-        const uint8_t* J = pyrJ + g.img_off[level];
-        const uint32_t* D = pyrD + g.img_off[level];
+        // first element of the padded level: all window offsets below are >= 0
+        const size_t pad0 = g.img_off[level] - (size_t)g.bh * S - g.bw;
+        const uint8_t* I = pyrI + pad0;
+        const uint8_t* J = pyrJ + pad0;
+        const uint32_t* D = pyrD + pad0;
 
         float prev_x = p0.x * a.lscale[level], prev_y = p0.y * a.lscale[level];
         float next_x, next_y;
@@ -293,47 +438,49 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
         }
         Weights wt = bilinear_weights(prev_x - ipx, prev_y - ipy);
 
-        int pA11 = 0, pA12 = 0, pA22 = 0;
+        int pA[3] = {0, 0, 0};
 #pragma unroll
         for (int s = 0; s < SPL; ++s) {
-            const ptrdiff_t o = (ptrdiff_t)(ipy + srow[s]) * S + ipx + sx0[s];
-            int r0[8], r1[8];
-            unpack8(load_u8x8(I + o), r0);
-            unpack8(load_u8x8(I + o + S), r1);
+            SlotWin& w = win[s];
+            const unsigned o = (unsigned)((ipy + g.bh + srow[s]) * S + ipx + g.bw + sx0[s]);
+            uint32_t i01, i23, i45;
+            int i6;
+            window_interp(I + o, S, wt, i01, i23, i45, i6);
+            w.i01 = i01 & w.m01;
+            w.i23 = i23 & w.m23;
+            w.i45 = i45 & w.m45;
+            w.i6 = i6 & w.m6;
             uint32_t d0[8], d1[8];
-            {
-                uint32_t tmp[8];
-                __builtin_memcpy(tmp, D + o, 32);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d0[j] = tmp[j];
-                __builtin_memcpy(tmp, D + o + S, 32);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d1[j] = tmp[j];
-            }
+            __builtin_memcpy(d0, D + o, 32);
+            __builtin_memcpy(d1, D + o + S, 32);
+            int ix[kPxPerSlot], iy[kPxPerSlot];
 #pragma unroll
             for (int j = 0; j < kPxPerSlot; ++j) {
-                const bool on = j < snpx[s];
-                const int ival = interp_px(r0[j], r0[j + 1], r1[j], r1[j + 1], wt);
-                const int x00 = (int)(short)(d0[j] & 0xFFFF), x01 = (int)(short)(d0[j + 1] & 0xFFFF);
-                const int x10 = (int)(short)(d1[j] & 0xFFFF), x11 = (int)(short)(d1[j + 1] & 0xFFFF);
-                const int y00 = (int)d0[j] >> 16, y01 = (int)d0[j + 1] >> 16;
-                const int y10 = (int)d1[j] >> 16, y11 = (int)d1[j + 1] >> 16;
-                int ixval = (x00 * wt.w00 + x01 * wt.w01 + x10 * wt.w10 + x11 * wt.w11 +
-                             (1 << (W_BITS - 1))) >> W_BITS;
-                int iyval = (y00 * wt.w00 + y01 * wt.w01 + y10 * wt.w10 + y11 * wt.w11 +
-                             (1 << (W_BITS - 1))) >> W_BITS;
-                ixval = on ? ixval : 0;
-                iyval = on ? iyval : 0;
-                Iw[s][j] = on ? ival : 0;
-                dIw[s][j] = ((uint32_t)ixval & 0xFFFFu) | ((uint32_t)iyval << 16);
-                pA11 += ixval * ixval;
-                pA12 += ixval * iyval;
-                pA22 += iyval * iyval;
+                // (Ix[j], Ix[j+1]) and (Iy[j], Iy[j+1]) as signed 16-bit pairs, rows y and y+1
+                const uint32_t x0 = __builtin_amdgcn_perm(d0[j + 1], d0[j], 0x05040100u);
+                const uint32_t y0 = __builtin_amdgcn_perm(d0[j + 1], d0[j], 0x07060302u);
+                const uint32_t x1 = __builtin_amdgcn_perm(d1[j + 1], d1[j], 0x05040100u);
+                const uint32_t y1 = __builtin_amdgcn_perm(d1[j + 1], d1[j], 0x07060302u);
+                ix[j] = interp_deriv(x0, x1, wt);
+                iy[j] = interp_deriv(y0, y1, wt);
             }
+            w.x01 = pack16(ix[0], ix[1]) & w.m01;
+            w.x23 = pack16(ix[2], ix[3]) & w.m23;
+            w.x45 = pack16(ix[4], ix[5]) & w.m45;
+            w.x6 = ix[6] & w.m6;
+            w.y01 = pack16(iy[0], iy[1]) & w.m01;
+            w.y23 = pack16(iy[2], iy[3]) & w.m23;
+            w.y45 = pack16(iy[4], iy[5]) & w.m45;
+            w.y6 = iy[6] & w.m6;
+            pA[0] = mad24(w.x6, w.x6, sdot2(w.x45, w.x45, sdot2(w.x23, w.x23, sdot2(w.x01, w.x01, pA[0]))));
+            pA[1] = mad24(w.x6, w.y6, sdot2(w.x45, w.y45, sdot2(w.x23, w.y23, sdot2(w.x01, w.y01, pA[1]))));
+            pA[2] = mad24(w.y6, w.y6, sdot2(w.y45, w.y45, sdot2(w.y23, w.y23, sdot2(w.y01, w.y01, pA[2]))));
         }
-        const float A11 = (float)wave_sum_wide(pA11) * FLT_SCALE;
-        const float A12 = (float)wave_sum_wide(pA12) * FLT_SCALE;
-        const float A22 = (float)wave_sum_wide(pA22) * FLT_SCALE;
+        long long sA[3];
+        wave_sum_wide_n<3, SPL == 1>(pA, sA);
+        const float A11 = (float)sA[0] * FLT_SCALE;
+        const float A12 = (float)sA[1] * FLT_SCALE;
+        const float A22 = (float)sA[2] * FLT_SCALE;
 
         float D_ = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
@@ -355,23 +502,25 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
                 break;
             }
             wt = bilinear_weights(next_x - inx, next_y - iny);
-            int pb1 = 0, pb2 = 0;
+            int pb[2] = {0, 0};
 #pragma unroll
             for (int s = 0; s < SPL; ++s) {
-                const ptrdiff_t o = (ptrdiff_t)(iny + srow[s]) * S + inx + sx0[s];
-                int r0[8], r1[8];
-                unpack8(load_u8x8(J + o), r0);
-                unpack8(load_u8x8(J + o + S), r1);
-#pragma unroll
-                for (int k = 0; k < kPxPerSlot; ++k) {
-                    const int diff = interp_px(r0[k], r0[k + 1], r1[k], r1[k + 1], wt) - Iw[s][k];
-                    const int dx = (int)(short)(dIw[s][k] & 0xFFFF), dy = (int)dIw[s][k] >> 16;
-                    pb1 += diff * dx;  // dx == dy == 0 outside the window
-                    pb2 += diff * dy;
-                }
+                const SlotWin& w = win[s];
+                const unsigned o = (unsigned)((iny + g.bh + srow[s]) * S + inx + g.bw + sx0[s]);
+                uint32_t j01, j23, j45;
+                int j6;
+                window_interp(J + o, S, wt, j01, j23, j45, j6);
+                // mismatch J - I; the derivative pairs are 0 outside the window
+                const uint32_t d01 = pk_sub_i16(j01, w.i01), d23 = pk_sub_i16(j23, w.i23),
+                               d45 = pk_sub_i16(j45, w.i45);
+                const int d6 = j6 - w.i6;
+                pb[0] = mad24(d6, w.x6, sdot2(d45, w.x45, sdot2(d23, w.x23, sdot2(d01, w.x01, pb[0]))));
+                pb[1] = mad24(d6, w.y6, sdot2(d45, w.y45, sdot2(d23, w.y23, sdot2(d01, w.y01, pb[1]))));
             }
-            const float b1 = (float)wave_sum_wide(pb1) * FLT_SCALE;
-            const float b2 = (float)wave_sum_wide(pb2) * FLT_SCALE;
+            long long sb[2];
+            wave_sum_wide_n<2, SPL == 1>(pb, sb);
+            const float b1 = (float)sb[0] * FLT_SCALE;
+            const float b2 = (float)sb[1] * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D_;
             const float dy = (A12 * b1 - A11 * b2) * D_;
             next_x += dx;
@@ -395,22 +544,27 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
                 status = 0;
             } else {
                 wt = bilinear_weights(ex - inx, ey - iny);
-                int perr = 0;
+                int perr[1] = {0};
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) {
-                    const ptrdiff_t o = (ptrdiff_t)(iny + srow[s]) * S + inx + sx0[s];
-                    int r0[8], r1[8];
-                    unpack8(load_u8x8(J + o), r0);
-                    unpack8(load_u8x8(J + o + S), r1);
+                    const SlotWin& w = win[s];
+                    const unsigned o = (unsigned)((iny + g.bh + srow[s]) * S + inx + g.bw + sx0[s]);
+                    uint32_t j01, j23, j45;
+                    int j6;
+                    window_interp(J + o, S, wt, j01, j23, j45, j6);
+                    const uint32_t dd[3] = {pk_sub_i16(j01, w.i01) & w.m01, pk_sub_i16(j23, w.i23) & w.m23,
+                                            pk_sub_i16(j45, w.i45) & w.m45};
 #pragma unroll
-                    for (int k = 0; k < kPxPerSlot; ++k) {
-                        const int diff = interp_px(r0[k], r0[k + 1], r1[k], r1[k + 1], wt) - Iw[s][k];
-                        perr += k < snpx[s] ? abs(diff) : 0;
+                    for (int k = 0; k < 3; ++k) {
+                        const int lo = (int)(short)(dd[k] & 0xFFFF), hi = (int)dd[k] >> 16;
+                        perr[0] += abs(lo) + abs(hi);
                     }
+                    perr[0] += abs((j6 - w.i6) & w.m6);
                 }
                 // Sum of |diff| stays below 2^24 for windows up to 41x41, so the float
                 // accumulation of the reference is exact and equals this integer sum.
-                const float errval = (float)wave_sum(perr);
+                wave_sum_n<1>(perr);
+                const float errval = (float)perr[0];
                 err = errval * 1.f / (float)(32 * a.win_w * a.win_h);
             }
         }
@@ -445,10 +599,9 @@ int make_geom(int width, int height, int win_w, int win_h, int max_level, LkGeom
         g->w[l] = w;
         g->h[l] = h;
         // 8 extra columns: a slot's 8-element loads may run past the window
-        g->stride[l] = (int)align_up((size_t)w + 2 * win_w + 8, 4);
+        g->stride[l] = (int)align_up((size_t)w + 2 * win_w + 8, 16);
+        // every padded row starts 16-byte aligned (off is a multiple of 64)
         g->img_off[l] = off + (size_t)win_h * g->stride[l] + (size_t)win_w;
-        // keep every level's first padded element 4-aligned
-        g->img_off[l] = align_up(g->img_off[l] - win_w, 4) + win_w;
         off = align_up(g->img_off[l] - win_w + (size_t)(h + win_h) * g->stride[l] + 64, 64);
         w = (w + 1) / 2;
         h = (h + 1) / 2;
@@ -549,7 +702,7 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     const dim3 blk(256);
     {
         const int S = g.stride[0];
-        const dim3 grid((S / 4 + 255) / 256, g.h[0] + 2 * g.bh, 2 * n_pairs);
+        const dim3 grid(((S / 16) * (g.h[0] + 2 * g.bh) + 255) / 256, 1, 2 * n_pairs);
         KernelTimer timer(ctx, KID_LK_PAD_LEVEL0);
         hipLaunchKernelGGL(lk_pad_level0_kernel, grid, blk, 0, ctx->stream, d_prev, d_curr,
                            image_stride, stride, g, bufs.pyr_prev, bufs.pyr_curr);
@@ -557,7 +710,7 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     }
     for (int l = 1; l <= g.levels; ++l) {
         const int S = g.stride[l];
-        const dim3 grid((S / 4 + 255) / 256, g.h[l] + 2 * g.bh, 2 * n_pairs);
+        const dim3 grid(((S / 4) * (g.h[l] + 2 * g.bh) + 255) / 256, 1, 2 * n_pairs);
         KernelTimer timer(ctx, KID_LK_PYR_DOWN);
         hipLaunchKernelGGL(lk_pyr_down_kernel, grid, blk, 0, ctx->stream, g, l, bufs.pyr_prev,
                            bufs.pyr_curr);

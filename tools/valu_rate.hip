@@ -1,0 +1,143 @@
+// Microbenchmark: sustained issue rate of individual VALU instructions on gfx950.
+// Each wave runs a long unrolled stream of independent instructions of one kind;
+// the grid fills every SIMD with `WAVES` waves.  Prints wave-instructions/s and
+// the implied cycles per wave64 instruction per SIMD at the measured clock.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+constexpr int ITERS = 2000;
+constexpr int UNROLL = 32;  // 8 independent chains x 4
+
+template <int OP>
+__global__ __launch_bounds__(256) void rate_kernel(unsigned* out, unsigned seed) {
+    unsigned v[8];
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = seed * (i + 1) + threadIdx.x; f[i] = (float)v[i]; }
+    unsigned k = seed | 1u;
+    float fk = 1.0001f;
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int u = 0; u < UNROLL / 8; ++u) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (OP == 0) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 1) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(v[i]) : "v"(k));
+                if (OP == 2) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 3) asm volatile("v_med3_u32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "v"(seed));
+                if (OP == 4) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 5) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[i]) : "v"(fk));
+                if (OP == 6) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 7) asm volatile("v_min_u32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 8) asm volatile("v_mad_i32_i24 %0, %0, %1, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 9) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 10) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(v[i]));
+                if (OP == 11) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[i]) : "v"(fk));
+                if (OP == 12) asm volatile("v_and_b32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 13) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(*(double*)&v[i & 6]) : "v"((double)fk));
+                if (OP == 14) asm volatile("v_dot4_u32_u8 %0, %0, %1, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 15) asm volatile("v_dot2_u32_u16 %0, %0, %1, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 16) asm volatile("v_dot2c_i32_i16 %0, %1, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 17) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "v"(seed));
+                if (OP == 18) asm volatile("v_alignbyte_b32 %0, %0, %1, 2" : "+v"(v[i]) : "v"(k));
+                if (OP == 19) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 20) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 21) asm volatile("v_mad_i32_i16 %0, %0, %1, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 22) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(v[i]), "v"(k) : "vcc");
+                if (OP == 23) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 24) asm volatile("v_or_b32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 25) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(v[i]));
+                if (OP == 26) asm volatile("v_ashrrev_i32 %0, 9, %0" : "+v"(v[i]));
+                if (OP == 27) asm volatile("v_max_u32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 28) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[i]) : "v"(fk));
+                if (OP == 29) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(*(double*)&v[i & 6]) : "v"((double)fk));
+                if (OP == 30) asm volatile("v_add_f64 %0, %0, %1" : "+v"(*(double*)&v[i & 6]) : "v"((double)fk));
+                if (OP == 31) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*(double*)&v[i & 6]) : "v"((double)fk));
+                if (OP == 32) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(k) : );
+                if (OP == 33) asm volatile("v_mov_b32 %0, %1" : "=v"(v[i]) : "v"(k));
+                if (OP == 34) asm volatile("s_nop 0\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v[i]));
+                if (OP == 35) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "v"(seed));
+                if (OP == 36) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "v"(seed));
+                if (OP == 37) asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "v"(seed));
+                if (OP == 38) asm volatile("v_sad_u8 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "v"(seed));
+            }
+        }
+    }
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += v[i] + (unsigned)f[i];
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <int OP>
+int run(const char* name, int waves_per_simd, unsigned* d_out) {
+    const int blocks = 256 * waves_per_simd;  // 256 CUs, 4 waves per block -> one wave per SIMD per block
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    rate_kernel<OP><<<blocks, 256>>>(d_out, 7);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) rate_kernel<OP><<<blocks, 256>>>(d_out, 7);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double instr = 5.0 * blocks * 4 * (double)ITERS * UNROLL;  // wave-instructions
+    const double per_simd_per_s = instr / (ms * 1e-3) / 1024.0;
+    printf("%-16s waves/SIMD=%d  %.3f ms  %.2f T lane-ops/s  %.2f cycles/wave-instr @2.4GHz\n", name,
+           waves_per_simd, ms / 5, instr * 64 / (ms * 1e-3) / 1e12, 2.4e9 / per_simd_per_s);
+    return 0;
+}
+
+int main() {
+    unsigned* d_out;
+    CHECK(hipMalloc(&d_out, 64));
+    for (int w : {4, 8}) {
+        run<14>("v_dot4_u32_u8", w, d_out);
+        run<15>("v_dot2_u32_u16", w, d_out);
+        run<16>("v_dot2c_i32_i16", w, d_out);
+        run<17>("v_perm_b32", w, d_out);
+        run<18>("v_alignbyte_b32", w, d_out);
+        run<19>("v_mul_lo_u32", w, d_out);
+        run<20>("v_mul_u32_u24", w, d_out);
+        run<21>("v_mad_i32_i16", w, d_out);
+        run<22>("v_cmp_lt_u32", w, d_out);
+        run<23>("v_sub_u32", w, d_out);
+        run<24>("v_or_b32", w, d_out);
+        run<25>("v_lshlrev_b32", w, d_out);
+        run<26>("v_ashrrev_i32", w, d_out);
+        run<27>("v_max_u32", w, d_out);
+        run<28>("v_add_f32", w, d_out);
+        run<29>("v_mul_f64", w, d_out);
+        run<30>("v_add_f64", w, d_out);
+        run<31>("v_pk_fma_f32", w, d_out);
+        run<32>("v_cndmask_b32", w, d_out);
+        run<33>("v_mov_b32", w, d_out);
+        run<34>("nop+v_add_dpp", w, d_out);
+        run<35>("v_min3_u32", w, d_out);
+        run<36>("v_xad_u32", w, d_out);
+        run<37>("v_bfi_b32", w, d_out);
+        run<38>("v_sad_u8", w, d_out);
+    }
+    for (int w : {1, 2, 4, 8}) {
+        run<0>("v_xor_b32", w, d_out);
+        run<1>("v_bcnt_u32_b32", w, d_out);
+        run<2>("v_add_u32", w, d_out);
+        run<3>("v_med3_u32", w, d_out);
+        run<4>("v_lshl_or_b32", w, d_out);
+        run<7>("v_min_u32", w, d_out);
+        run<6>("v_mad_u32_u24", w, d_out);
+        run<8>("v_mad_i32_i24", w, d_out);
+        run<9>("v_add3_u32", w, d_out);
+        run<10>("v_bfe_u32", w, d_out);
+        run<12>("v_and_b32", w, d_out);
+        run<5>("v_fma_f32", w, d_out);
+        run<11>("v_mul_f32", w, d_out);
+        run<13>("v_fma_f64", w, d_out);
+    }
+    return 0;
+}
