@@ -269,7 +269,9 @@ KnnPlan make_knn_plan(const sfm_ctx* ctx, int norm, int d, int nq_max, int nt_ma
     const long want = (long)per_cu * ctx->num_cus;
     long blocks = (long)qtiles * n_problems;
     int splits = (int)((want + blocks - 1) / blocks);
-    const int max_splits = (nt_max + 2 * tile_rows - 1) / (2 * tile_rows);
+    // at least 64 train rows per split
+    (void)tile_rows;
+    const int max_splits = (nt_max + 63) / 64;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     p.splits = splits;

@@ -272,6 +272,49 @@ __device__ __forceinline__ void wave_sum_wide_n(const int (&p)[N], long long (&o
     for (int i = 0; i < N; ++i) out[i] = (long long)h[2 * i + 1] * 65536 + h[2 * i];
 }
 
+// Sums over the 16 lanes of each DPP row, result in every lane of the row: two
+// quad permutes, then the half-row and full-row mirrors.
+template <int N>
+__device__ __forceinline__ void row_sum_n(int (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0xB1, 0xF>(v[i]);   // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x4E, 0xF>(v[i]);   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x141, 0xF>(v[i]);  // row_half_mirror
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x140, 0xF>(v[i]);  // row_mirror
+}
+
+// Exact per-row sums of N int32 partials (|partial| < 2^30) as (low 16 bits, high part)
+// halves: one add in 32 bits (two lanes cannot overflow), then the halves separately.
+template <int N>
+__device__ __forceinline__ void row_sum_wide_n(const int (&p)[N], int (&lo)[N], int (&hi)[N]) {
+    int h[2 * N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int v = dpp_add<0xB1, 0xF>(p[i]);
+        h[2 * i] = v & 0xFFFF;
+        h[2 * i + 1] = v >> 16;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * N; ++i) h[i] = dpp_add<0x4E, 0xF>(h[i]);
+#pragma unroll
+    for (int i = 0; i < 2 * N; ++i) h[i] = dpp_add<0x141, 0xF>(h[i]);
+#pragma unroll
+    for (int i = 0; i < 2 * N; ++i) h[i] = dpp_add<0x140, 0xF>(h[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        lo[i] = h[2 * i];
+        hi[i] = h[2 * i + 1];
+    }
+}
+
+// (float)(hi * 65536 + lo) with one rounding: both terms and their sum are exact in double.
+__device__ __forceinline__ float halves_to_float(int hi, int lo) {
+    return (float)((double)hi * 65536.0 + (double)lo);
+}
+
 __device__ __forceinline__ uint2 load_u8x8(const uint8_t* p) {
     uint2 v;
     __builtin_memcpy(&v, p, 8);
@@ -371,11 +414,16 @@ __device__ __forceinline__ void window_interp(const uint8_t* row0, int S, const 
     p45 = pack16(s4, s5);
 }
 
-template <int SPL>
+// LPP = lanes per point: 64 (one point per wave) or 16 (four points per wave, one per
+// DPP row; the per-point scalar work is then shared by four points per instruction).
+template <int LPP, int SPL>
 __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int pt = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pt >= a.n_total) return;  // wave-uniform
+    const int lane = threadIdx.x & (LPP - 1);
+    const int pt_raw = (blockIdx.x * 256 + threadIdx.x) / LPP;
+    if (LPP == 64 && pt_raw >= a.n_total) return;  // wave-uniform
+    if (LPP == 16 && (pt_raw & ~3) >= a.n_total) return;  // whole wave past the end
+    const bool pt_live = pt_raw < a.n_total;
+    const int pt = pt_live ? pt_raw : a.n_total - 1;  // surplus rows repeat the last point
     const int pair = pt / a.n;
     const LkGeom& g = a.g;
     const uint8_t* pyrI = a.pyr_prev + (size_t)pair * g.block;
@@ -387,7 +435,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
     SlotWin win[SPL];
 #pragma unroll
     for (int s = 0; s < SPL; ++s) {
-        const int slot = lane + 64 * s;
+        const int slot = lane + LPP * s;
         const bool valid = slot < a.slots;
         const int sl = valid ? slot : 0;
         srow[s] = sl / a.segs;
@@ -476,11 +524,20 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
             pA[1] = mad24(w.x6, w.y6, sdot2(w.x45, w.y45, sdot2(w.x23, w.y23, sdot2(w.x01, w.y01, pA[1]))));
             pA[2] = mad24(w.y6, w.y6, sdot2(w.y45, w.y45, sdot2(w.y23, w.y23, sdot2(w.y01, w.y01, pA[2]))));
         }
-        long long sA[3];
-        wave_sum_wide_n<3, SPL == 1>(pA, sA);
-        const float A11 = (float)sA[0] * FLT_SCALE;
-        const float A12 = (float)sA[1] * FLT_SCALE;
-        const float A22 = (float)sA[2] * FLT_SCALE;
+        float A11, A12, A22;
+        if (LPP == 64) {
+            long long sA[3];
+            wave_sum_wide_n<3, SPL == 1>(pA, sA);
+            A11 = (float)sA[0] * FLT_SCALE;
+            A12 = (float)sA[1] * FLT_SCALE;
+            A22 = (float)sA[2] * FLT_SCALE;
+        } else {
+            int lo[3], hi[3];
+            row_sum_wide_n<3>(pA, lo, hi);
+            A11 = halves_to_float(hi[0], lo[0]) * FLT_SCALE;
+            A12 = halves_to_float(hi[1], lo[1]) * FLT_SCALE;
+            A22 = halves_to_float(hi[2], lo[2]) * FLT_SCALE;
+        }
 
         float D_ = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
@@ -517,10 +574,18 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
                 pb[0] = mad24(d6, w.x6, sdot2(d45, w.x45, sdot2(d23, w.x23, sdot2(d01, w.x01, pb[0]))));
                 pb[1] = mad24(d6, w.y6, sdot2(d45, w.y45, sdot2(d23, w.y23, sdot2(d01, w.y01, pb[1]))));
             }
-            long long sb[2];
-            wave_sum_wide_n<2, SPL == 1>(pb, sb);
-            const float b1 = (float)sb[0] * FLT_SCALE;
-            const float b2 = (float)sb[1] * FLT_SCALE;
+            float b1, b2;
+            if (LPP == 64) {
+                long long sb[2];
+                wave_sum_wide_n<2, SPL == 1>(pb, sb);
+                b1 = (float)sb[0] * FLT_SCALE;
+                b2 = (float)sb[1] * FLT_SCALE;
+            } else {
+                int lo[2], hi[2];
+                row_sum_wide_n<2>(pb, lo, hi);
+                b1 = halves_to_float(hi[0], lo[0]) * FLT_SCALE;
+                b2 = halves_to_float(hi[1], lo[1]) * FLT_SCALE;
+            }
             const float dx = (A12 * b2 - A22 * b1) * D_;
             const float dy = (A12 * b1 - A11 * b2) * D_;
             next_x += dx;
@@ -563,7 +628,10 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
                 }
                 // Sum of |diff| stays below 2^24 for windows up to 41x41, so the float
                 // accumulation of the reference is exact and equals this integer sum.
-                wave_sum_n<1>(perr);
+                if (LPP == 64)
+                    wave_sum_n<1>(perr);
+                else
+                    row_sum_n<1>(perr);
                 const float errval = (float)perr[0];
                 err = errval * 1.f / (float)(32 * a.win_w * a.win_h);
             }
@@ -571,7 +639,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
     }
 
     if (err > a.max_error) status = 0;  // feature_processing.cpp:245-248
-    if (lane == 0) {
+    if (lane == 0 && pt_live) {
         a.next_pts[pt] = make_float2(out_x, out_y);
         a.status[pt] = (uint8_t)status;
         if (a.err) a.err[pt] = err;
@@ -743,14 +811,23 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     a.next_pts = reinterpret_cast<float2*>(d_curr_pts);
     a.status = d_status;
     a.err = d_err;
-    const int spl = (a.slots + 63) / 64;
-    const dim3 grid((a.n_total + 3) / 4);
     KernelTimer timer(ctx, KID_LK_TRACK);
-    switch (spl) {
-        case 1: hipLaunchKernelGGL(lk_track_kernel<1>, grid, blk, 0, ctx->stream, a); break;
-        case 2: hipLaunchKernelGGL(lk_track_kernel<2>, grid, blk, 0, ctx->stream, a); break;
-        case 3: hipLaunchKernelGGL(lk_track_kernel<3>, grid, blk, 0, ctx->stream, a); break;
-        default: hipLaunchKernelGGL(lk_track_kernel<4>, grid, blk, 0, ctx->stream, a); break;
+    if (a.slots <= 64) {
+        // four points per wave, 16 lanes each
+        const dim3 grid((a.n_total + 15) / 16);
+        switch ((a.slots + 15) / 16) {
+            case 1: hipLaunchKernelGGL((lk_track_kernel<16, 1>), grid, blk, 0, ctx->stream, a); break;
+            case 2: hipLaunchKernelGGL((lk_track_kernel<16, 2>), grid, blk, 0, ctx->stream, a); break;
+            case 3: hipLaunchKernelGGL((lk_track_kernel<16, 3>), grid, blk, 0, ctx->stream, a); break;
+            default: hipLaunchKernelGGL((lk_track_kernel<16, 4>), grid, blk, 0, ctx->stream, a); break;
+        }
+    } else {
+        const dim3 grid((a.n_total + 3) / 4);
+        switch ((a.slots + 63) / 64) {
+            case 2: hipLaunchKernelGGL((lk_track_kernel<64, 2>), grid, blk, 0, ctx->stream, a); break;
+            case 3: hipLaunchKernelGGL((lk_track_kernel<64, 3>), grid, blk, 0, ctx->stream, a); break;
+            default: hipLaunchKernelGGL((lk_track_kernel<64, 4>), grid, blk, 0, ctx->stream, a); break;
+        }
     }
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;

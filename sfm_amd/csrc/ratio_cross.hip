@@ -2,11 +2,11 @@
 //
 // Replaces the host loops of DescriptorMatcher::ratioMaches (Source Files/
 // feature_processing.cpp:126-129) and the cross-check of findRobustMatches
-// (:159-176).  One 1024-lane workgroup handles one frame pair: it merges the
-// per-split keys of both directions, applies  d0 < ratio * d1  in float exactly
-// as the reference does, then walks the backward list in ascending curr index
-// (the reference's output order) and keeps the pairs whose forward match points
-// back, compacting them with a ballot / prefix-popcount scan.
+// (:159-176).  A first kernel merges the per-split keys of both directions and
+// applies  d0 < ratio * d1  in float exactly as the reference does; a second one
+// (one 1024-lane workgroup per frame pair) walks the backward list in ascending
+// curr index (the reference's output order) and keeps the pairs whose forward
+// match points back, compacting them with a ballot / prefix-popcount scan.
 #include "sfm_internal.h"
 
 namespace sfm {
@@ -41,6 +41,49 @@ __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
+// Phase 1: merge the per-split keys (or read the re-scored neighbours) and apply the
+// ratio test.  One lane per query row; grid.y = problem (two per pair).
+__global__ __launch_bounds__(256) void merge_ratio_kernel(CrossArgs a) {
+    const int problem = blockIdx.y, pair = problem >> 1, dir = problem & 1;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int fa = a.pairs[2 * pair], fb = a.pairs[2 * pair + 1];
+    const int n_prev = a.counts ? a.counts[fa] : a.n_prev_uniform;
+    const int n_curr = a.counts ? a.counts[fb] : a.n_curr_uniform;
+    const int nq = dir ? n_curr : n_prev;
+    const int nt = dir ? n_prev : n_curr;
+    if (q >= nq) return;
+    const uint32_t mask = (1u << kIdxBits) - 1;
+    float d0, d1;
+    int32_t i0, i1;
+    if (a.keys) {
+        const uint2* keys = a.keys + (size_t)problem * a.splits * (size_t)a.rows_max;
+        uint32_t m1 = kNoKey, m2 = kNoKey;
+        for (int s = 0; s < a.splits; ++s) {
+            const uint2 k = keys[(size_t)s * a.rows_max + q];
+            m2 = med3_u32(m1, m2, k.x);
+            m1 = min(m1, k.x);
+            m2 = med3_u32(m1, m2, k.y);
+            m1 = min(m1, k.y);
+        }
+        d0 = (float)(m1 >> kIdxBits);
+        d1 = (float)(m2 >> kIdxBits);
+        i0 = m1 == kNoKey ? -1 : (int32_t)(m1 & mask);
+        i1 = m2 == kNoKey ? -1 : (int32_t)(m2 & mask);
+    } else {
+        const size_t o = ((size_t)problem * a.rows_max + q) * 2;
+        i0 = a.knn_idx[o];
+        i1 = a.knn_idx[o + 1];
+        d0 = a.knn_dist[o];
+        d1 = a.knn_dist[o + 1];
+    }
+    // feature_processing.cpp:127, float * float, strict <
+    const bool pass = nt >= 2 && i1 >= 0 && d0 < a.ratio * d1;
+    a.best[(size_t)problem * a.rows_max + q] = pass ? i0 : -1;
+    a.best_dist[(size_t)problem * a.rows_max + q] = d0;
+}
+
+// Phase 2: walk the backward list in ascending curr index and keep the pairs whose
+// forward match points back, compacted in order.  One workgroup per pair.
 __global__ __launch_bounds__(kThreads) void ratio_cross_kernel(CrossArgs a) {
     __shared__ int wave_count[kThreads / 64];
     const int pair = blockIdx.x;
@@ -48,43 +91,6 @@ __global__ __launch_bounds__(kThreads) void ratio_cross_kernel(CrossArgs a) {
     const int fa = a.pairs[2 * pair], fb = a.pairs[2 * pair + 1];
     const int n_prev = a.counts ? a.counts[fa] : a.n_prev_uniform;
     const int n_curr = a.counts ? a.counts[fb] : a.n_curr_uniform;
-    const uint32_t mask = (1u << kIdxBits) - 1;
-
-    for (int dir = 0; dir < 2; ++dir) {
-        const int nq = dir ? n_curr : n_prev;
-        const int nt = dir ? n_prev : n_curr;
-        const size_t problem = 2 * (size_t)pair + dir;
-        const uint2* keys = a.keys ? a.keys + problem * a.splits * (size_t)a.rows_max : nullptr;
-        for (int q = tid; q < nq; q += kThreads) {
-            float d0, d1;
-            int32_t i0, i1;
-            if (a.keys) {
-                uint32_t m1 = kNoKey, m2 = kNoKey;
-                for (int s = 0; s < a.splits; ++s) {
-                    const uint2 k = keys[(size_t)s * a.rows_max + q];
-                    m2 = med3_u32(m1, m2, k.x);
-                    m1 = min(m1, k.x);
-                    m2 = med3_u32(m1, m2, k.y);
-                    m1 = min(m1, k.y);
-                }
-                d0 = (float)(m1 >> kIdxBits);
-                d1 = (float)(m2 >> kIdxBits);
-                i0 = m1 == kNoKey ? -1 : (int32_t)(m1 & mask);
-                i1 = m2 == kNoKey ? -1 : (int32_t)(m2 & mask);
-            } else {
-                const size_t o = (problem * a.rows_max + q) * 2;
-                i0 = a.knn_idx[o];
-                i1 = a.knn_idx[o + 1];
-                d0 = a.knn_dist[o];
-                d1 = a.knn_dist[o + 1];
-            }
-            // feature_processing.cpp:127, float * float, strict <
-            const bool pass = nt >= 2 && i1 >= 0 && d0 < a.ratio * d1;
-            a.best[problem * a.rows_max + q] = pass ? i0 : -1;
-            a.best_dist[problem * a.rows_max + q] = d0;
-        }
-    }
-    __syncthreads();  // the block's own global writes are visible to it afterwards
 
     const int32_t* fwd = a.best + (2 * (size_t)pair) * a.rows_max;
     const int32_t* bwd = fwd + a.rows_max;
@@ -193,6 +199,12 @@ int launch_ratio_cross(sfm_ctx* ctx, const KnnPlan& plan, const uint32_t* d_keys
     a.matches = d_matches;
     a.cap = cap;
     a.match_counts = d_match_counts;
+    {
+        KernelTimer timer(ctx, KID_MERGE_RATIO);
+        hipLaunchKernelGGL(merge_ratio_kernel, dim3((a.rows_max + 255) / 256, 2 * n_pairs), dim3(256),
+                           0, ctx->stream, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
     KernelTimer timer(ctx, KID_RATIO_CROSS);
     hipLaunchKernelGGL(ratio_cross_kernel, dim3(n_pairs), dim3(kThreads), 0, ctx->stream, a);
     SFM_HIP_CHECK(ctx, hipGetLastError());
@@ -221,6 +233,12 @@ int launch_ratio_cross_knn(sfm_ctx* ctx, const int32_t* d_knn_idx, const float* 
     a.matches = d_matches;
     a.cap = cap;
     a.match_counts = d_match_counts;
+    {
+        KernelTimer timer(ctx, KID_MERGE_RATIO);
+        hipLaunchKernelGGL(merge_ratio_kernel, dim3((a.rows_max + 255) / 256, 2 * n_pairs), dim3(256),
+                           0, ctx->stream, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
     KernelTimer timer(ctx, KID_RATIO_CROSS);
     hipLaunchKernelGGL(ratio_cross_kernel, dim3(n_pairs), dim3(kThreads), 0, ctx->stream, a);
     SFM_HIP_CHECK(ctx, hipGetLastError());

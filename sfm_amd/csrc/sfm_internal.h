@@ -16,6 +16,7 @@ namespace sfm {
 enum KernelId {
     KID_HAMMING_KNN2 = 0,
     KID_RATIO_CROSS,
+    KID_MERGE_RATIO,
     KID_KNN_FINALIZE,
     KID_PACK_ROWS,
     KID_RATIO_COMPACT,
