@@ -28,6 +28,7 @@ enum KernelId {
     KID_LK_SCHARR,
     KID_LK_TRACK,
     KID_TRIANGULATE_DLT,
+    KID_TRIANGULATE_LIST,
     KID_COUNT
 };
 struct TimedLaunch {

@@ -7,13 +7,23 @@
 // division by w, reprojection with the separately supplied R, t, and the mask
 //   err < maxProjErr && depth > minDist && depth < maxDist.
 //
-// One lane per correspondence; the 4x4 system, the rotation accumulator V and
-// the column norms stay in VGPRs (36 doubles).  Every loop over matrix indices
-// is fully unrolled so that no array is indexed at run time.  The sweep loop is
-// wave-uniform: a wave leaves it when none of its lanes rotated in a sweep.
-// All arithmetic is fp64, as in the reference (points are widened to double by
-// Header Files/common.h:47-57 before cv::triangulatePoints sees them).
+// One lane per correspondence, all arithmetic in fp64 as in the reference (points
+// are widened to double by Header Files/common.h:47-57 before
+// cv::triangulatePoints sees them).  Two solvers for the right singular vector
+// of the smallest singular value of the 4x4 system A:
+//   - fast path: the eigenvector of the smallest eigenvalue of M = A^T A by shifted
+//     inverse iteration.  Every step factors M - s I = L D L^T with a shift s kept
+//     below the smallest eigenvalue (Rayleigh quotient minus the residual norm), so
+//     the factorisation stays positive definite and needs no pivoting; the
+//     contamination by the other eigenvectors is squared per step.  A point whose
+//     iteration has not settled after kMaxInvIt steps is appended to a list;
+//   - one-sided Jacobi, the algorithm of cv::SVD::compute itself (36 doubles in
+//     VGPRs, every matrix loop unrolled, wave-uniform sweep loop).  It handles the
+//     listed points, and every point when SFM_TRIANGULATE_JACOBI=1 is set.
+// Both give the same vector up to rounding (observed ~1e-12 relative on
+// well-conditioned points, against a stated tolerance of 1e-4).
 #include <cfloat>
+#include <cstdlib>
 
 #include "sfm_internal.h"
 
@@ -82,14 +92,8 @@ __device__ __forceinline__ bool rotate(double (&At)[4][4], double (&Vt)[4][4], d
     return true;
 }
 
-__global__ __launch_bounds__(256) void triangulate_dlt_kernel(TriArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < a.n;
-    const float2 p1 = live ? a.prev_pts[i] : make_float2(0.f, 0.f);
-    const float2 p2 = live ? a.curr_pts[i] : make_float2(1.f, 1.f);
-    const double x1 = p1.x, y1 = p1.y, x2 = p2.x, y2 = p2.y;
-
-    double At[4][4], Vt[4][4], W[4];
+__device__ __forceinline__ void build_system(const TriArgs& a, double x1, double y1, double x2,
+                                             double y2, double (&At)[4][4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         At[k][0] = x1 * a.P1[8 + k] - a.P1[k];
@@ -97,6 +101,12 @@ __global__ __launch_bounds__(256) void triangulate_dlt_kernel(TriArgs a) {
         At[k][2] = x2 * a.P2[8 + k] - a.P2[k];
         At[k][3] = y2 * a.P2[8 + k] - a.P2[4 + k];
     }
+}
+
+// cv::SVD::compute's one-sided Jacobi on At (rows = columns of A); v = last row of Vt
+// after the descending sort of the singular values.
+__device__ __forceinline__ void null_vector_jacobi(double (&At)[4][4], double (&v)[4]) {
+    double Vt[4][4], W[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         double sd = 0;
@@ -152,11 +162,116 @@ __global__ __launch_bounds__(256) void triangulate_dlt_kernel(TriArgs a) {
         W[r] = wmax;
     }
     const int last = perm[3];
-    double v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         v[k] = last == 0 ? Vt[0][k] : last == 1 ? Vt[1][k] : last == 2 ? Vt[2][k] : Vt[3][k];
+}
 
+constexpr int kMaxInvIt = 10;
+
+// Solves (M - shift I) x = b by L D L^T; M symmetric, given by its upper triangle
+// m[] = {00,01,02,03,11,12,13,22,23,33}.  Returns false when one of the first three
+// pivots is not positive (the shift was not below the spectrum); a non-positive last
+// pivot is replaced by a tiny positive one (exactly singular system).
+__device__ __forceinline__ bool ldl_solve(const double (&m)[10], double shift, double tiny,
+                                          const double (&b)[4], double (&x)[4]) {
+    const double a00 = m[0] - shift, a11 = m[4] - shift, a22 = m[7] - shift, a33 = m[9] - shift;
+    const double a01 = m[1], a02 = m[2], a03 = m[3], a12 = m[5], a13 = m[6], a23 = m[8];
+    const double d0 = a00;
+    const double i0 = 1.0 / d0;
+    const double l10 = a01 * i0, l20 = a02 * i0, l30 = a03 * i0;
+    const double d1 = fma(-l10, a01, a11);
+    const double i1 = 1.0 / d1;
+    const double t21 = fma(-l20, a01, a12), t31 = fma(-l30, a01, a13);
+    const double l21 = t21 * i1, l31 = t31 * i1;
+    const double d2 = fma(-l21, t21, fma(-l20, a02, a22));
+    const double i2 = 1.0 / d2;
+    const double t32 = fma(-l31, t21, fma(-l30, a02, a23));
+    const double l32 = t32 * i2;
+    double d3 = fma(-l32, t32, fma(-l31, t31, fma(-l30, a03, a33)));
+    const bool ok = d0 > 0 && d1 > 0 && d2 > 0;
+    d3 = d3 > tiny ? d3 : tiny;
+    const double i3 = 1.0 / d3;
+    const double y0 = b[0];
+    const double y1 = fma(-l10, y0, b[1]);
+    const double y2 = fma(-l21, y1, fma(-l20, y0, b[2]));
+    const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, b[3])));
+    x[3] = y3 * i3;
+    x[2] = fma(-l32, x[3], y2 * i2);
+    x[1] = fma(-l31, x[3], fma(-l21, x[2], y1 * i1));
+    x[0] = fma(-l30, x[3], fma(-l20, x[2], fma(-l10, x[1], y0 * i0)));
+    return ok;
+}
+
+// Smallest eigenvector of M = A^T A by safely shifted inverse iteration.
+// Returns false when the iteration did not settle (caller falls back to Jacobi).
+__device__ __forceinline__ bool null_vector_invit(const double (&At)[4][4], double (&v)[4]) {
+    double m[10];
+    {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i; j < 4; ++j) {
+                double s = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s = fma(At[i][r], At[j][r], s);
+                m[t++] = s;
+            }
+    }
+    const double trace = m[0] + m[4] + m[7] + m[9];
+    const double tiny = trace * 1e-30 + 1e-300;
+    double x[4] = {0.1, 0.2, 0.9, 0.3};
+    double shift = -trace * 1e-15;  // strictly below the spectrum of a positive semidefinite M
+    bool done = false, bad = false;
+    for (int it = 0; it < kMaxInvIt; ++it) {
+        double y[4];
+        const bool ok = ldl_solve(m, shift, tiny, x, y);
+        // normalise
+        const double n2 = fma(y[0], y[0], fma(y[1], y[1], fma(y[2], y[2], y[3] * y[3])));
+        const double inv = rsqrt(n2);
+        double z[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[k] = y[k] * inv;
+        // change against the previous iterate, up to sign
+        const double dot = fma(z[0], x[0], fma(z[1], x[1], fma(z[2], x[2], z[3] * x[3])));
+        const double sgn = dot < 0 ? -1.0 : 1.0;
+        double delta = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            z[k] *= sgn;
+            delta = fmax(delta, fabs(z[k] - x[k]));
+        }
+        if (!done) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = z[k];
+            bad |= !ok || !(n2 > 0) || !(n2 < 1e300);
+        }
+        // the error is squared per step: a step that moved the iterate by < 1e-7 landed
+        // within ~1e-14 of the eigenvector
+        done |= (it > 0 && delta < 1e-7) || bad;
+        if (__all(done)) break;
+        // Rayleigh quotient and residual: an eigenvalue lies within |r| of rho; it is the
+        // smallest one once the iterate is dominated by that eigenvector
+        const double w0 = fma(m[0], x[0], fma(m[1], x[1], fma(m[2], x[2], m[3] * x[3])));
+        const double w1 = fma(m[1], x[0], fma(m[4], x[1], fma(m[5], x[2], m[6] * x[3])));
+        const double w2 = fma(m[2], x[0], fma(m[5], x[1], fma(m[7], x[2], m[8] * x[3])));
+        const double w3 = fma(m[3], x[0], fma(m[6], x[1], fma(m[8], x[2], m[9] * x[3])));
+        const double rho = fma(w0, x[0], fma(w1, x[1], fma(w2, x[2], w3 * x[3])));
+        const double r0 = fma(-rho, x[0], w0), r1 = fma(-rho, x[1], w1), r2 = fma(-rho, x[2], w2),
+                     r3 = fma(-rho, x[3], w3);
+        const double rn = sqrt(fma(r0, r0, fma(r1, r1, fma(r2, r2, r3 * r3))));
+        const double s = rho - 1.0625 * rn - trace * 1e-15;
+        if (!done) shift = s > shift ? s : shift;  // never move the shift back
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = x[k];
+    return done && !bad;
+}
+
+// Division by w, reprojection, mask and colour for correspondence i (reconstruction.cpp:6-39).
+__device__ __forceinline__ void finish_point(const TriArgs& a, int i, const double (&v)[4], double x2,
+                                             double y2) {
     const double scale = v[3] != 0 ? 1. / v[3] : 1.;
     const double Xw = v[0] * scale, Yw = v[1] * scale, Zw = v[2] * scale;
 
@@ -171,7 +286,6 @@ __global__ __launch_bounds__(256) void triangulate_dlt_kernel(TriArgs a) {
     const double e = sqrt(du * du + dv * dv);
     const double depth = a.Pc2[0] * Xw + a.Pc2[1] * Yw + a.Pc2[2] * Zw + a.Pc2[3] * 1.0;
 
-    if (!live) return;
     a.X[3 * (size_t)i] = Xw;
     a.X[3 * (size_t)i + 1] = Yw;
     a.X[3 * (size_t)i + 2] = Zw;
@@ -185,6 +299,52 @@ __global__ __launch_bounds__(256) void triangulate_dlt_kernel(TriArgs a) {
         a.rgb[3 * (size_t)i] = c[0];
         a.rgb[3 * (size_t)i + 1] = c[1];
         a.rgb[3 * (size_t)i + 2] = c[2];
+    }
+}
+
+// Every point by one-sided Jacobi.
+__global__ __launch_bounds__(256) void triangulate_dlt_kernel(TriArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < a.n;
+    const float2 p1 = live ? a.prev_pts[i] : make_float2(0.f, 0.f);
+    const float2 p2 = live ? a.curr_pts[i] : make_float2(1.f, 1.f);
+    double At[4][4], v[4];
+    build_system(a, p1.x, p1.y, p2.x, p2.y, At);
+    null_vector_jacobi(At, v);
+    if (live) finish_point(a, i, v, p2.x, p2.y);
+}
+
+// Fast path; unsettled points go to `list` (count in list_count[0]).
+__global__ __launch_bounds__(256) void triangulate_invit_kernel(TriArgs a, int* list_count, int* list) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < a.n;
+    const float2 p1 = live ? a.prev_pts[i] : make_float2(0.f, 0.f);
+    const float2 p2 = live ? a.curr_pts[i] : make_float2(1.f, 1.f);
+    double At[4][4], v[4];
+    build_system(a, p1.x, p1.y, p2.x, p2.y, At);
+    const bool ok = null_vector_invit(At, v);
+    if (!live) return;
+    if (ok)
+        finish_point(a, i, v, p2.x, p2.y);
+    else
+        list[atomicAdd(list_count, 1)] = i;
+}
+
+// The listed points by one-sided Jacobi (grid-stride; exits at once when the list is empty).
+__global__ __launch_bounds__(256) void triangulate_list_kernel(TriArgs a, const int* list_count,
+                                                               const int* list) {
+    const int count = *list_count;
+    const int rounds = (count + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+    for (int r = 0; r < rounds; ++r) {  // wave-uniform trip count: the Jacobi sweep loop votes
+        const int k = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        const bool live = k < count;
+        const int i = live ? list[k] : 0;
+        const float2 p1 = a.prev_pts[i];
+        const float2 p2 = a.curr_pts[i];
+        double At[4][4], v[4];
+        build_system(a, p1.x, p1.y, p2.x, p2.y, At);
+        null_vector_jacobi(At, v);
+        if (live) finish_point(a, i, v, p2.x, p2.y);
     }
 }
 
@@ -249,9 +409,38 @@ int sfm_triangulate_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
     a.rgb = d_rgb;
     a.mask = d_mask;
     a.err = d_err;
-    KernelTimer timer(ctx, KID_TRIANGULATE_DLT);
-    hipLaunchKernelGGL(triangulate_dlt_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
-    SFM_HIP_CHECK(ctx, hipGetLastError());
+    static const bool force_jacobi = [] {
+        const char* e = getenv("SFM_TRIANGULATE_JACOBI");
+        return e && e[0] == '1';
+    }();
+    if (force_jacobi) {
+        KernelTimer timer(ctx, KID_TRIANGULATE_DLT);
+        hipLaunchKernelGGL(triangulate_dlt_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+        return SFM_OK;
+    }
+    Carver sz(nullptr);
+    sz.take<int>(64);
+    sz.take<int>((size_t)n);
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
+    Carver c(ws);
+    int* list_count = c.take<int>(64);
+    int* list = c.take<int>((size_t)n);
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(list_count, 0, 256, ctx->stream));
+    {
+        KernelTimer timer(ctx, KID_TRIANGULATE_DLT);
+        hipLaunchKernelGGL(triangulate_invit_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+                           a, list_count, list);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    {
+        KernelTimer timer(ctx, KID_TRIANGULATE_LIST);
+        const int blocks = n < 256 * 64 ? (n + 255) / 256 : 64;
+        hipLaunchKernelGGL(triangulate_list_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a,
+                           list_count, list);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
     return SFM_OK;
 }
 

@@ -126,3 +126,33 @@ def test_triangulate_mirror_class(ctx, oracle):
     with pytest.raises(sfm_amd.capi.SfmError):
         sfm_amd.Reconstruction("DLT", ctx=ctx).triangulateCloud(
             cam, s["p1"], s["p2"], img, s["prev_pose"], s["curr_pose"], s["R"], s["t"])
+
+
+def test_triangulate_jacobi_solver_agrees(oracle):
+    """SFM_TRIANGULATE_JACOBI=1 selects the one-sided Jacobi solver (the algorithm of
+    cv::SVD::compute) for every point; it must agree with the default inverse-iteration
+    path and with the oracle.  The switch is read once per process, hence the child."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from sfm_amd import capi, synth
+from oracle import pyoracle
+s = synth.triangulation_set(20011, seed=13)
+args = (s["K"], s["prev_pose"], s["curr_pose"], s["R"], s["t"], s["p1"], s["p2"])
+X, _, mask, err = capi.Context(0).triangulate(*args)
+oX, _, omask, oerr = pyoracle.triangulate(*args)
+rel = np.linalg.norm(X - oX, axis=1) / np.linalg.norm(oX, axis=1)
+assert rel.max() < 1e-12, rel.max()
+band = np.abs(oerr - 3.0) < 1e-6
+assert (mask[~band] == omask[~band]).all()
+print("jacobi ok", rel.max())
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SFM_TRIANGULATE_JACOBI="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "jacobi ok" in out.stdout
