@@ -153,13 +153,44 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
     if (ntiles > 0) stage(0, 0);
     __syncthreads();
 
-    for (int k = 0; k < ntiles; ++k) {
+    // Two accumulator sets.  While the matrix pipe accumulates tile k into one set, the
+    // vector ALU folds the finished tile k-1 (the other set) into the best-two lists, a
+    // slice of it after every group of MFMAs, so the fold hides in the MFMA issue shadow.
+    constexpr int kMSteps = K / 8;
+    constexpr int kGroups = 2 * NT * 4;  // groups of 4 accumulator registers per set
+    floatx16 accA[2][NT], accB[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accA[mt][n][r] = accB[mt][n][r] = INFINITY;
+
+    // Keeps the two smallest keys per lane and query tile.  Candidates arrive in ascending
+    // train index and comparisons are strict, so equal keys keep the lower index first; a
+    // key that displaces the best pushes the old best (not the old second) down.
+    auto fold_group = [&](const floatx16 (&acc)[2][NT], int tbase, int gi) {
+        const int mt = gi / (NT * 4), n = (gi / 4) % NT, gq = gi % 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float key = acc[mt][n][4 * gq + r];
+            const int ti = tbase + 32 * mt + 8 * gq + 4 * lh + r;
+            const bool c0 = key < best0[n], c1 = key < best1[n];
+            const float t = c1 ? key : best1[n];
+            const int tix = c1 ? ti : bidx1[n];
+            best1[n] = c0 ? best0[n] : t;
+            bidx1[n] = c0 ? bidx0[n] : tix;
+            best0[n] = c0 ? key : best0[n];
+            bidx0[n] = c0 ? ti : bidx0[n];
+        }
+    };
+
+    auto tile_step = [&](floatx16 (&accC)[2][NT], const floatx16 (&accF)[2][NT], int k) {
         const int buf = k & 1;
         if (k + 1 < ntiles) stage(k + 1, buf ^ 1);
         const float* tile = lds + buf * kTileFloats;
         const float* nrm = norm_lds + buf * kTileRows;
-
-        floatx16 acc[2][NT];
+        const int tbase_prev = t_begin + (k - 1) * kTileRows;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             // accumulator register r of this lane is train row 32mt + 8(r>>2) + 4lh + (r&3)
@@ -173,60 +204,51 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
                 init[4 * gq + 3] = v.w;
             }
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[mt][n] = init;
+            for (int n = 0; n < NT; ++n) accC[mt][n] = init;
         }
-
-#pragma unroll
-        for (int m = 0; m < K / 8; ++m) {
-            floatx4 av[2];
+        auto load_av = [&](int m, floatx4 (&av)[2]) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int row = 32 * mt + li;
                 const int cpos = (2 * m + lh) ^ (row & 15);
                 av[mt] = *reinterpret_cast<const floatx4*>(tile + row * K + cpos * 4);
             }
+        };
+        floatx4 av[2], av_next[2];
+        load_av(0, av);
+#pragma unroll
+        for (int m = 0; m < kMSteps; ++m) {
+            if (m + 1 < kMSteps) load_av(m + 1, av_next);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        acc[mt][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][s], qreg[n][m][s],
-                                                                          acc[mt][n], 0, 0, 0);
+                        accC[mt][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][s], qreg[n][m][s],
+                                                                           accC[mt][n], 0, 0, 0);
+#pragma unroll
+            for (int gi = (m * kGroups) / kMSteps; gi < ((m + 1) * kGroups) / kMSteps; ++gi)
+                fold_group(accF, tbase_prev, gi);
+            av[0] = av_next[0];
+            av[1] = av_next[1];
         }
-
-        // keep the two smallest keys per lane and query tile; candidates arrive in
-        // ascending train index, so strict comparisons keep the lower index on ties
-        const int tbase = t_begin + k * kTileRows;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const floatx16& c = acc[mt][n];
-                    const float lo = fminf(fminf(c[4 * gq], c[4 * gq + 1]),
-                                           fminf(c[4 * gq + 2], c[4 * gq + 3]));
-                    if (__any(lo < best1[n])) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float key = c[4 * gq + r];
-                            const int ti = tbase + 32 * mt + 8 * gq + 4 * lh + r;
-                            if (key < best1[n]) {
-                                if (key < best0[n]) {
-                                    best1[n] = best0[n];
-                                    bidx1[n] = bidx0[n];
-                                    best0[n] = key;
-                                    bidx0[n] = ti;
-                                } else {
-                                    best1[n] = key;
-                                    bidx1[n] = ti;
-                                }
-                            }
-                        }
-                    }
-                }
         __syncthreads();
+    };
+
+    for (int k = 0; k < ntiles; k += 2) {
+        tile_step(accA, accB, k);
+        if (k + 1 < ntiles) tile_step(accB, accA, k + 1);
+    }
+    {
+        const int tbase_last = t_begin + (ntiles - 1) * kTileRows;
+        if (ntiles & 1) {
+#pragma unroll
+            for (int gi = 0; gi < kGroups; ++gi) fold_group(accA, tbase_last, gi);
+        } else if (ntiles > 0) {
+#pragma unroll
+            for (int gi = 0; gi < kGroups; ++gi) fold_group(accB, tbase_last, gi);
+        }
     }
 
     int32_t* cand = a.cand + (((size_t)problem * a.splits + split) * a.rows_cap) * 4;
@@ -306,11 +328,18 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
     }
     unsigned long long key = ~0ull;
     if (ti >= 0) {
-        const float* trow = trows + (size_t)ti * a.K;
+        // Scalar order of OpenCV's normL2Sqr; rows are zero-padded to K floats and
+        // (0 - 0)^2 adds an exact zero, so running to K changes nothing.
+        const floatx4* q4 = reinterpret_cast<const floatx4*>(qrow);
+        const floatx4* t4 = reinterpret_cast<const floatx4*>(trows + (size_t)ti * a.K);
         float d = 0.f;
-        for (int j = 0; j < a.dim; ++j) {  // scalar order of OpenCV's normL2Sqr
-            const float v = qrow[j] - trow[j];
-            d += v * v;
+        for (int j = 0; j < a.K / 4; ++j) {
+            const floatx4 qa = q4[j], ta = t4[j];
+            const float v0 = qa.x - ta.x, v1 = qa.y - ta.y, v2 = qa.z - ta.z, v3 = qa.w - ta.w;
+            d += v0 * v0;
+            d += v1 * v1;
+            d += v2 * v2;
+            d += v3 * v3;
         }
         if (!a.squared) d = sqrtf(d);  // batchDistL2_32f
         key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)ti;
@@ -345,13 +374,25 @@ int make_l2_plan(const sfm_ctx* ctx, int dim, int nq_max, int nt_max, int n_prob
     }
     p->q_per_block = 4 * 32 * p->NT;
     p->qtiles = (nq_max + p->q_per_block - 1) / p->q_per_block;
-    const long want = 4L * ctx->num_cus;
-    const long blocks = (long)p->qtiles * n_problems;
-    int splits = (int)((want + blocks - 1) / blocks);
-    const int max_splits = (nt_max + 2 * kTileRows - 1) / (2 * kTileRows);
-    if (splits > max_splits) splits = max_splits;
-    if (splits > kMaxSplits) splits = kMaxSplits;
-    if (splits < 1) splits = 1;
+    // One workgroup per CU fits (register file), so the launch runs in rounds of num_cus
+    // workgroups: pick the split count (<= kMaxSplits, >= 128 train rows each) that wastes
+    // the least in the last round and in the partial last tile; ties go to fewer splits.
+    const long base = (long)p->qtiles * n_problems;
+    int splits = 1;
+    double best_eff = -1.0;
+    for (int sp = 1; sp <= kMaxSplits; ++sp) {
+        const int chunk = (nt_max + sp - 1) / sp;
+        if (sp > 1 && chunk < 2 * kTileRows) break;
+        const long blocks = base * sp;
+        const long rounds = (blocks + ctx->num_cus - 1) / ctx->num_cus;
+        const int tiles = (chunk + kTileRows - 1) / kTileRows;
+        const double eff = (double)blocks / (double)(rounds * ctx->num_cus) * (double)chunk /
+                           (double)(tiles * kTileRows);
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            splits = sp;
+        }
+    }
     p->splits = splits;
     return SFM_OK;
 }
