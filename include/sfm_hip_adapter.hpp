@@ -1,0 +1,422 @@
+/*
+ * sfm_hip_adapter.hpp -- header-only C++ host side over the C ABI in sfm_hip.h.
+ *
+ * It gives the three wrapper classes of the reference the same public
+ * interface they have there, with bodies that call the MI355X library:
+ *
+ *   sfm_hip::DescriptorMatcher  Header Files/feature_processing.h:33-57
+ *   sfm_hip::OptFlow            Header Files/feature_processing.h:59-100
+ *   sfm_hip::Reconstruction     Header Files/reconstruction.h:140-159
+ *                               (constructor and triangulateCloud only)
+ *
+ * With OpenCV's headers on the include path the classes take and return the
+ * OpenCV types the reference passes (cv::Mat, cv::KeyPoint, cv::DMatch, ...),
+ * so Source Files/app_solver.cpp compiles against them unchanged.  Without
+ * OpenCV (define SFM_ADAPTER_NO_OPENCV, or simply have no <opencv2/core.hpp>)
+ * a small set of stand-in types with the same member names and memory layout
+ * is used instead, which is how this repository tests the adapter.
+ *
+ * Objects are cheap to copy: the reference passes them by value
+ * (Header Files/app_solver.h:120, Header Files/tracking.h:88), so the GPU
+ * context is held through a shared handle.
+ */
+#ifndef SFM_HIP_ADAPTER_HPP
+#define SFM_HIP_ADAPTER_HPP
+
+#include <algorithm>
+#include <cctype>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "sfm_hip.h"
+
+#if !defined(SFM_ADAPTER_NO_OPENCV) && defined(__has_include)
+#if __has_include(<opencv2/core.hpp>)
+#define SFM_ADAPTER_HAVE_OPENCV 1
+#endif
+#endif
+
+#ifdef SFM_ADAPTER_HAVE_OPENCV
+#include <opencv2/calib3d.hpp>
+#include <opencv2/core.hpp>
+#include <opencv2/features2d.hpp>
+namespace sfm_hip {
+namespace cvx = cv;
+inline bool mat_is_u8(const cv::Mat& m) { return m.depth() == CV_8U; }
+inline bool mat_is_f32(const cv::Mat& m) { return m.depth() == CV_32F; }
+inline int mat_channels(const cv::Mat& m) { return m.channels(); }
+inline size_t mat_step(const cv::Mat& m) { return m.step[0]; }
+[[noreturn]] inline void raise(const std::string& what) {
+    CV_Error(cv::Error::StsError, what);
+}
+}  // namespace sfm_hip
+#else
+namespace sfm_hip {
+/* Stand-ins for the OpenCV types at the boundary: same member names, and for
+ * the plain structs the same layout, as OpenCV 4's. */
+namespace cvx {
+typedef unsigned char uchar;
+struct Point2f {
+    float x, y;
+    Point2f() : x(0), y(0) {}
+    Point2f(float x_, float y_) : x(x_), y(y_) {}
+};
+struct Size {
+    int width, height;
+    Size() : width(0), height(0) {}
+    Size(int w, int h) : width(w), height(h) {}
+};
+struct KeyPoint { /* 28 bytes, as cv::KeyPoint */
+    Point2f pt;
+    float size, angle, response;
+    int octave, class_id;
+    KeyPoint() : size(0), angle(-1), response(0), octave(0), class_id(-1) {}
+    KeyPoint(float x, float y, float s) : pt(x, y), size(s), angle(-1), response(0), octave(0), class_id(-1) {}
+};
+struct DMatch { /* 16 bytes, as cv::DMatch */
+    int queryIdx, trainIdx, imgIdx;
+    float distance;
+    DMatch() : queryIdx(-1), trainIdx(-1), imgIdx(-1), distance(3.402823466e+38f) {}
+};
+template <typename T, int N>
+struct Vec {
+    T val[N];
+    Vec() { for (int i = 0; i < N; ++i) val[i] = T(0); }
+    T& operator[](int i) { return val[i]; }
+    const T& operator[](int i) const { return val[i]; }
+};
+typedef Vec<double, 3> Vec3d;
+typedef Vec<uchar, 3> Vec3b;
+template <int R, int C>
+struct Matx {
+    double val[R * C];
+    Matx() { for (int i = 0; i < R * C; ++i) val[i] = 0.0; }
+    double& operator()(int r, int c) { return val[r * C + c]; }
+    const double& operator()(int r, int c) const { return val[r * C + c]; }
+};
+typedef Matx<3, 3> Matx33d;
+typedef Matx<3, 4> Matx34d;
+typedef Matx<3, 1> Matx31d;
+struct TermCriteria {
+    enum Type { COUNT = 1, MAX_ITER = COUNT, EPS = 2 };
+    int type, maxCount;
+    double epsilon;
+    TermCriteria() : type(0), maxCount(0), epsilon(0) {}
+    TermCriteria(int t, int c, double e) : type(t), maxCount(c), epsilon(e) {}
+};
+/* Dense row-major 2-D array of u8 or f32 with 1 or 3 channels. */
+struct Mat {
+    enum Depth { U8 = 0, F32 = 5 };
+    int rows, cols, depth_, channels_;
+    size_t step;
+    uchar* data;
+    std::shared_ptr<std::vector<uchar>> storage;
+    Mat() : rows(0), cols(0), depth_(U8), channels_(1), step(0), data(nullptr) {}
+    Mat(int r, int c, Depth d, int ch = 1)
+        : rows(r), cols(c), depth_(d), channels_(ch),
+          step(size_t(c) * ch * (d == F32 ? 4 : 1)),
+          storage(std::make_shared<std::vector<uchar>>(size_t(r) * step)) {
+        data = storage->data();
+    }
+    /* Wraps memory the caller keeps alive. */
+    Mat(int r, int c, Depth d, int ch, void* p, size_t step_bytes)
+        : rows(r), cols(c), depth_(d), channels_(ch), step(step_bytes), data(static_cast<uchar*>(p)) {}
+    bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+};
+}  // namespace cvx
+inline bool mat_is_u8(const cvx::Mat& m) { return m.depth_ == cvx::Mat::U8; }
+inline bool mat_is_f32(const cvx::Mat& m) { return m.depth_ == cvx::Mat::F32; }
+inline int mat_channels(const cvx::Mat& m) { return m.channels_; }
+inline size_t mat_step(const cvx::Mat& m) { return m.step; }
+[[noreturn]] inline void raise(const std::string& what) { throw std::runtime_error(what); }
+}  // namespace sfm_hip
+#endif
+
+namespace sfm_hip {
+
+static_assert(sizeof(cvx::DMatch) == sizeof(sfm_dmatch), "DMatch must be 16 bytes");
+static_assert(sizeof(cvx::Point2f) == 8, "Point2f must be two floats");
+
+/* Shared GPU context; one per device is enough for the reference's single
+ * main-loop thread (Source Files/app_solver.cpp:151). */
+class Handle {
+public:
+    explicit Handle(int device = 0) {
+        sfm_ctx* raw = nullptr;
+        if (sfm_ctx_create(device, &raw) != SFM_OK) raise(std::string("sfm_ctx_create: ") + sfm_last_error(nullptr));
+        ctx_.reset(raw, sfm_ctx_destroy);
+    }
+    sfm_ctx* get() const { return ctx_.get(); }
+    void check(int status, const char* call) const {
+        if (status != SFM_OK) raise(std::string(call) + ": " + sfm_last_error(ctx_.get()));
+    }
+    static Handle& shared() {
+        static Handle h(0);
+        return h;
+    }
+
+private:
+    std::shared_ptr<sfm_ctx> ctx_;
+};
+
+/* Header Files/feature_processing.h:33-57.  `matcher` (a cv::Ptr to OpenCV's
+ * matcher there) becomes the norm the constructor selects. */
+class DescriptorMatcher {
+public:
+    const bool m_isVisDebug;
+    const float m_ratioThreshold;
+    const cvx::Size m_visDebugWinSize;
+    int normType; /* SFM_NORM_* */
+    Handle handle;
+
+    /* Optional epipolar filter (points -> inlier mask), the step at
+     * Source Files/feature_processing.cpp:187-188 that stays with the caller.
+     * With OpenCV present it defaults to cv::findFundamentalMat. */
+    std::function<void(const std::vector<cvx::Point2f>&, const std::vector<cvx::Point2f>&, std::vector<uint8_t>&)>
+        epipolarFilter;
+
+    /* Source Files/feature_processing.cpp:101-116. */
+    DescriptorMatcher(std::string method, const float ratioThreshold, const bool isVisDebug = false,
+                      const cvx::Size visDebugWinSize = cvx::Size(), Handle h = Handle::shared())
+        : m_isVisDebug(isVisDebug), m_ratioThreshold(ratioThreshold),
+          m_visDebugWinSize(cvx::Size(visDebugWinSize.width * 2, visDebugWinSize.height * 3)), handle(h) {
+        std::for_each(method.begin(), method.end(), [](char& c) { c = char(::toupper(c)); });
+        if (method == "BRUTEFORCE_HAMMING") normType = SFM_NORM_HAMMING;
+        else if (method == "BRUTEFORCE_SL2") normType = SFM_NORM_L2SQR;
+        else if (method == "FLANNBASED") raise("FLANNBASED matching is approximate and not provided by sfm_hip");
+        else normType = SFM_NORM_L2;
+#ifdef SFM_ADAPTER_HAVE_OPENCV
+        epipolarFilter = [](const std::vector<cv::Point2f>& a, const std::vector<cv::Point2f>& b, std::vector<uint8_t>& m) {
+            cv::findFundamentalMat(a, b, m);
+        };
+#endif
+    }
+
+    /* Source Files/feature_processing.cpp:118-130. */
+    void ratioMaches(const cvx::Mat lDesc, const cvx::Mat rDesc, std::vector<cvx::DMatch>& matches) {
+        matches.clear();
+        if (lDesc.empty()) return;
+        const int d = checkedDim(lDesc, rDesc);
+        std::vector<cvx::DMatch> out(size_t(lDesc.rows));
+        int count = 0;
+        handle.check(sfm_ratio_matches(handle.get(), normType, lDesc.data, lDesc.rows, mat_step(lDesc), rDesc.data,
+                                       rDesc.rows, mat_step(rDesc), d, m_ratioThreshold,
+                                       reinterpret_cast<sfm_dmatch*>(out.data()), &count),
+                     "sfm_ratio_matches");
+        out.resize(size_t(count));
+        matches.swap(out);
+    }
+
+    /* Source Files/feature_processing.cpp:144-226.  The two ratio matches and
+     * the cross-check run on the GPU as one call; the lists are appended to,
+     * as in the reference. */
+    void findRobustMatches(std::vector<cvx::KeyPoint> prevKeyPts, std::vector<cvx::KeyPoint> currKeyPts,
+                           cvx::Mat prevDesc, cvx::Mat currDesc, std::vector<cvx::Point2f>& prevAligPts,
+                           std::vector<cvx::Point2f>& currAligPts, std::vector<cvx::DMatch>& matches,
+                           std::vector<int>& prevPtsToKeyIdx, std::vector<int>& currPtsToKeyIdx,
+                           cvx::Mat /*debugPrevFrame*/ = cvx::Mat(), cvx::Mat /*debugCurrFrame*/ = cvx::Mat(),
+                           bool useEpipolarFilter = false) {
+        if (!prevDesc.empty() && !currDesc.empty()) {
+            const int d = checkedDim(prevDesc, currDesc);
+            std::vector<cvx::DMatch> cross(size_t(std::min(prevDesc.rows, currDesc.rows)));
+            int count = 0;
+            handle.check(sfm_robust_matches(handle.get(), normType, prevDesc.data, prevDesc.rows, mat_step(prevDesc),
+                                            currDesc.data, currDesc.rows, mat_step(currDesc), d, m_ratioThreshold,
+                                            reinterpret_cast<sfm_dmatch*>(cross.data()), &count),
+                         "sfm_robust_matches");
+            for (int i = 0; i < count; ++i) {
+                const cvx::DMatch& m = cross[size_t(i)];
+                prevAligPts.push_back(prevKeyPts.at(size_t(m.queryIdx)).pt);
+                currAligPts.push_back(currKeyPts.at(size_t(m.trainIdx)).pt);
+                matches.push_back(m);
+            }
+        }
+        if (prevAligPts.empty() || currAligPts.empty()) return;
+
+        std::vector<uint8_t> inliers(matches.size(), 1);
+        if (useEpipolarFilter) {
+            if (!epipolarFilter) raise("useEpipolarFilter needs DescriptorMatcher::epipolarFilter to be set");
+            epipolarFilter(prevAligPts, currAligPts, inliers);
+        }
+        std::vector<cvx::DMatch> keptMatches;
+        std::vector<cvx::Point2f> keptPrev, keptCurr;
+        for (size_t m = 0; m < matches.size(); ++m) {
+            if (inliers[m] || !useEpipolarFilter) {
+                keptPrev.push_back(prevKeyPts.at(size_t(matches[m].queryIdx)).pt);
+                keptCurr.push_back(currKeyPts.at(size_t(matches[m].trainIdx)).pt);
+                prevPtsToKeyIdx.push_back(matches[m].queryIdx);
+                currPtsToKeyIdx.push_back(matches[m].trainIdx);
+                keptMatches.push_back(matches[m]);
+            }
+        }
+        std::swap(matches, keptMatches);
+        std::swap(prevAligPts, keptPrev);
+        std::swap(currAligPts, keptCurr);
+    }
+
+private:
+    /* OpenCV asserts that both descriptor sets have one type and width and
+     * that the type suits the norm; the same conditions raise here. */
+    int checkedDim(const cvx::Mat& l, const cvx::Mat& r) const {
+        if (mat_channels(l) != 1 || mat_channels(r) != 1) raise("descriptors must be single-channel");
+        if (l.cols != r.cols) raise("descriptor widths differ");
+        if (normType == SFM_NORM_HAMMING) {
+            if (!mat_is_u8(l) || !mat_is_u8(r)) raise("Hamming matching needs CV_8U descriptors");
+        } else if (!mat_is_f32(l) || !mat_is_f32(r)) {
+            raise("L2 matching needs CV_32F descriptors");
+        }
+        return l.cols;
+    }
+};
+
+/* Header Files/feature_processing.h:59-73. */
+class OptFlowAddSettings {
+public:
+    float maxError, qualLvl, minDist;
+    unsigned maxCorn, minFeatures;
+    void setMaxError(float v) { maxError = v; }
+    void setMaxCorners(unsigned v) { maxCorn = v; }
+    void setQualityLvl(float v) { qualLvl = v; }
+    void setMinDistance(float v) { minDist = v; }
+    void setMinFeatures(unsigned v) { minFeatures = v; }
+};
+
+/* What cv::SparsePyrLKOpticalFlow::create keeps
+ * (Source Files/feature_processing.cpp:229), with OpenCV's accessor names. */
+struct PyrLKSettings {
+    cvx::Size winSize;
+    int maxLevel;
+    cvx::TermCriteria criteria;
+    int flags;
+    double minEigThreshold;
+    cvx::Size getWinSize() const { return winSize; }
+    void setWinSize(cvx::Size s) { winSize = s; }
+    int getMaxLevel() const { return maxLevel; }
+    void setMaxLevel(int l) { maxLevel = l; }
+    cvx::TermCriteria getTermCriteria() const { return criteria; }
+    void setTermCriteria(const cvx::TermCriteria& c) { criteria = c; }
+    int getFlags() const { return flags; }
+    double getMinEigThreshold() const { return minEigThreshold; }
+    void setMinEigThreshold(double v) { minEigThreshold = v; }
+    PyrLKSettings* operator->() { return this; }
+    const PyrLKSettings* operator->() const { return this; }
+};
+
+/* Header Files/feature_processing.h:75-100 (constructor and computeFlow). */
+class OptFlow {
+public:
+    PyrLKSettings optFlow;
+    OptFlowAddSettings additionalSettings;
+    std::vector<cvx::uchar> statusMask;
+    Handle handle;
+
+    /* Source Files/feature_processing.cpp:228-236. */
+    OptFlow(cvx::TermCriteria termcrit, int winSize, int maxLevel, float maxError, unsigned maxCorners,
+            float qualityLevel, float minCornersDistance, unsigned minFeatures, Handle h = Handle::shared())
+        : handle(h) {
+        optFlow.winSize = cvx::Size(winSize, winSize);
+        optFlow.maxLevel = maxLevel;
+        optFlow.criteria = termcrit;
+        optFlow.flags = 0;
+        optFlow.minEigThreshold = 1e-4;
+        additionalSettings.setMaxError(maxError);
+        additionalSettings.setMaxCorners(maxCorners);
+        additionalSettings.setQualityLvl(qualityLevel);
+        additionalSettings.setMinDistance(minCornersDistance);
+        additionalSettings.setMinFeatures(minFeatures);
+    }
+
+    /* Source Files/feature_processing.cpp:238-249. */
+    void computeFlow(cvx::Mat imPrevGray, cvx::Mat imCurrGray, std::vector<cvx::Point2f>& prevPts,
+                     std::vector<cvx::Point2f>& currPts, std::vector<cvx::uchar>& statusMask_) {
+        const size_t n = prevPts.size();
+        currPts.resize(n);
+        statusMask_.resize(n);
+        if (n == 0) return;
+        if (!mat_is_u8(imPrevGray) || mat_channels(imPrevGray) != 1 || !mat_is_u8(imCurrGray) ||
+            mat_channels(imCurrGray) != 1)
+            raise("computeFlow needs 8-bit single-channel images");
+        if (imPrevGray.rows != imCurrGray.rows || imPrevGray.cols != imCurrGray.cols ||
+            mat_step(imPrevGray) != mat_step(imCurrGray))
+            raise("computeFlow needs two images of one size and row pitch");
+        handle.check(sfm_pyrlk(handle.get(), imPrevGray.data, imCurrGray.data, imPrevGray.cols, imPrevGray.rows,
+                               mat_step(imPrevGray), reinterpret_cast<const float*>(prevPts.data()), int(n),
+                               optFlow.winSize.width, optFlow.winSize.height, optFlow.maxLevel,
+                               int(optFlow.criteria.type), optFlow.criteria.maxCount, optFlow.criteria.epsilon,
+                               optFlow.minEigThreshold, additionalSettings.maxError,
+                               reinterpret_cast<float*>(currPts.data()), statusMask_.data(), nullptr),
+                     "sfm_pyrlk");
+    }
+};
+
+/* Header Files/reconstruction.h:140-159 (constructor and triangulateCloud).
+ * Camera is the reference's CameraParameters (Header Files/camera.h:11-42) or
+ * anything else with a K33d member. */
+class Reconstruction {
+public:
+    Reconstruction(const std::string triangulateMethod, const std::string baMethod, const double baMaxRMSE,
+                   const float minDistance, const float maxDistance, const float maxProjectionError,
+                   const bool useNormalizePts, Handle h = Handle::shared())
+        : m_triangulateMethod(triangulateMethod), m_baMethod(baMethod), m_baMaxRMSE(baMaxRMSE),
+          m_minDistance(minDistance), m_maxDistance(maxDistance), m_maxProjectionError(maxProjectionError),
+          m_useNormalizePts(useNormalizePts), handle(h) {}
+
+    /* Source Files/reconstruction.cpp:41-73 with :6-39.  points3D and
+     * pointsRGB are cleared and refilled, mask is appended to.  The undistort
+     * step there has no distortion coefficients, so both settings of
+     * useNormalizePts give the same points.  With triangulateMethod "DLT" the
+     * reference triangulates nothing (its call is commented out) and hands an
+     * empty matrix to cv::projectPoints; that configuration raises here. */
+    template <class Camera>
+    void triangulateCloud(Camera camera, const std::vector<cvx::Point2f> prevPts,
+                          const std::vector<cvx::Point2f> currPts, const cvx::Mat colorImage,
+                          std::vector<cvx::Vec3d>& points3D, std::vector<cvx::Vec3b>& pointsRGB,
+                          std::vector<bool>& mask, const cvx::Matx34d prevPose, const cvx::Matx34d currPose,
+                          cvx::Matx33d& R, cvx::Matx31d& t) {
+        if (prevPts.empty() || currPts.empty()) return;
+        if (m_triangulateMethod == "DLT")
+            raise("triangulateMethod \"DLT\" is a dead branch in the reference; use any other name");
+        if (prevPts.size() != currPts.size()) raise("triangulateCloud needs as many prev as curr points");
+        if (colorImage.empty() || !mat_is_u8(colorImage) || mat_channels(colorImage) != 3)
+            raise("triangulateCloud needs an 8-bit 3-channel colour image");
+        const int n = int(prevPts.size());
+        double K[9], P1[12], P2[12], Rm[9], tv[3];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) {
+                K[r * 3 + c] = camera.K33d(r, c);
+                Rm[r * 3 + c] = R(r, c);
+            }
+            for (int c = 0; c < 4; ++c) {
+                P1[r * 4 + c] = prevPose(r, c);
+                P2[r * 4 + c] = currPose(r, c);
+            }
+            tv[r] = t(r, 0);
+        }
+        points3D.resize(size_t(n));
+        pointsRGB.resize(size_t(n));
+        std::vector<uint8_t> m(static_cast<size_t>(n));
+        static_assert(sizeof(cvx::Vec3d) == 24 && sizeof(cvx::Vec3b) == 3, "Vec3d / Vec3b layout");
+        handle.check(sfm_triangulate(handle.get(), K, P1, P2, Rm, tv, reinterpret_cast<const float*>(prevPts.data()),
+                                     reinterpret_cast<const float*>(currPts.data()), n, colorImage.data,
+                                     colorImage.cols, colorImage.rows, mat_step(colorImage), m_minDistance,
+                                     m_maxDistance, m_maxProjectionError, reinterpret_cast<double*>(points3D.data()),
+                                     reinterpret_cast<uint8_t*>(pointsRGB.data()), m.data(), nullptr),
+                     "sfm_triangulate");
+        for (int i = 0; i < n; ++i) mask.push_back(m[size_t(i)] != 0);
+    }
+
+private:
+    const std::string m_triangulateMethod, m_baMethod;
+    const double m_baMaxRMSE;
+    const float m_minDistance, m_maxDistance, m_maxProjectionError;
+    const bool m_useNormalizePts;
+    Handle handle;
+};
+
+}  // namespace sfm_hip
+#endif /* SFM_HIP_ADAPTER_HPP */
