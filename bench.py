@@ -102,6 +102,24 @@ def timed_steps(step, steps, warmup, world, dev, ctx):
     return max_over_ranks(dt, world, dev), prof
 
 
+def pmc_traffic(workload, kernels):
+    """HBM bytes per launch of the first of `kernels` found in the newest committed
+    profiles/rNN_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this
+    same workload (tools/profile_round.sh), (2 x FETCH_SIZE + WRITE_SIZE) x 1024 with the gfx950
+    half-count correction of FETCH_SIZE.  None when no such record exists."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        rec = json.load(f).get(workload, {})
+    for k in kernels:
+        if k in rec and rec[k].get("hbm_bytes") is not None:
+            return rec[k]["hbm_bytes"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def kernel_line(prof, name):
     ms, n = prof.get(name, (0.0, 0))
     return {"total_ms": round(ms, 4), "launches": n, "avg_us": round(1e3 * ms / n, 3) if n else None}
@@ -217,6 +235,8 @@ def run_framepair(args, rank, world, local):
                                           f"{KPS}^2 x 16",
                 "traffic": None}
     roof_ham["frac"] = round(roof_ham["achieved"] / VALU_PEAK_TLANEOPS, 4) if ham_n else None
+    if P == 32:  # the PMC passes were taken at the default pairs per launch
+        roof_ham["traffic"], roof_ham["traffic_source"] = pmc_traffic("framepair", ["hamming_knn2_kernel"])
     out = {
         "metric": METRIC, "value": round(value, 1), "unit": "features/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -302,6 +322,8 @@ def run_c3(args, rank, world, local):
                                "sample": f"{m * 5} correspondences x {reps} passes, all threads; "
                                          f"1 thread: {m / t1:.0f}/s on {m}",
                                "one_thread_value": round(m / t1, 1)}
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(
+        "c3", ["triangulate_invit_kernel", "triangulate_dlt_kernel"])
     ctx.close()
     return out
 
@@ -352,6 +374,8 @@ def run_c4(args, rank, world, local):
         "roofline": main["roofline"],
         "variants": {k: {kk: vv for kk, vv in v.items() if kk != "_dt"} for k, v in res.items()},
     }
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(
+        "c4", ["l2_candidates_kernel"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle
 
