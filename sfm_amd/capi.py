@@ -131,9 +131,12 @@ class Context:
     @staticmethod
     def _desc(norm, a):
         dt = np.uint8 if norm == NORM_HAMMING else np.float32
-        a = np.ascontiguousarray(a, dtype=dt)
+        a = np.asarray(a, dtype=dt)
         if a.ndim != 2:
             raise ValueError("descriptors must be a 2-D array (rows x length)")
+        # rows may sit in a wider array (row pitch > row length); anything else is made dense
+        if not (a.shape[0] == 0 or (a.strides[1] == a.itemsize and a.strides[0] >= a.shape[1] * a.itemsize)):
+            a = np.ascontiguousarray(a)
         return a
 
     def knn2(self, norm, q, t):
@@ -199,10 +202,14 @@ class Context:
     def pyrlk(self, prev, curr, prev_pts, win=(21, 21), max_level=3,
               crit_type=TERM_COUNT | TERM_EPS, max_count=30, epsilon=0.01,
               min_eig_threshold=1e-4, max_error=10.0):
-        prev = np.ascontiguousarray(prev, dtype=np.uint8)
-        curr = np.ascontiguousarray(curr, dtype=np.uint8)
+        prev, curr = np.asarray(prev, dtype=np.uint8), np.asarray(curr, dtype=np.uint8)
         if prev.ndim != 2 or prev.shape != curr.shape:
             raise ValueError("images must be equal-size 8-bit single-channel arrays")
+        # rows may be a view into a wider image (a cv::Mat region of interest) as long as both
+        # images share one row pitch; anything else is made dense first
+        if not (prev.strides[1] == 1 and curr.strides[1] == 1 and
+                prev.strides[0] == curr.strides[0] >= prev.shape[1]):
+            prev, curr = np.ascontiguousarray(prev), np.ascontiguousarray(curr)
         h, w = prev.shape
         pts = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(-1, 2)
         n = pts.shape[0]

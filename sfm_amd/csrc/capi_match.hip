@@ -153,17 +153,16 @@ int sfm_knn2(sfm_ctx* ctx, int norm, const void* q, int nq, size_t q_stride, con
     uint8_t* dt = c.take<uint8_t>((size_t)nt * row);
     int32_t* di = c.take<int32_t>((size_t)nq * 2);
     float* dd = c.take<float>((size_t)nq * 2);
-    SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(dq, row, q, q_stride, row, nq, hipMemcpyHostToDevice,
-                                        ctx->stream));
+    SFM_RETURN_IF(upload_rows(ctx, dq, q, q_stride, row, (size_t)nq));
     if (nt > 0)
-        SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(dt, row, t, t_stride, row, nt, hipMemcpyHostToDevice,
-                                            ctx->stream));
+        SFM_RETURN_IF(upload_rows(ctx, dt, t, t_stride, row, (size_t)nt));
     SFM_RETURN_IF(sfm_knn2_dev(ctx, norm, dq, nq, row, dt, nt, row, d, di, dd));
     SFM_HIP_CHECK(ctx, hipMemcpyAsync(idx, di, sizeof(int32_t) * 2 * nq, hipMemcpyDeviceToHost,
                                       ctx->stream));
     SFM_HIP_CHECK(ctx, hipMemcpyAsync(dist, dd, sizeof(float) * 2 * nq, hipMemcpyDeviceToHost,
                                       ctx->stream));
     SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pinned_used = 0;
     return SFM_OK;
 }
 
@@ -196,16 +195,15 @@ int sfm_ratio_matches(sfm_ctx* ctx, int norm, const void* q, int nq, size_t q_st
     float* dd = c.take<float>((size_t)nq * 2);
     sfm_dmatch* dm = c.take<sfm_dmatch>((size_t)nq);
     int32_t* dc = c.take<int32_t>(4);
-    SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(dq, row, q, q_stride, row, nq, hipMemcpyHostToDevice,
-                                        ctx->stream));
-    SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(dt, row, t, t_stride, row, nt, hipMemcpyHostToDevice,
-                                        ctx->stream));
+    SFM_RETURN_IF(upload_rows(ctx, dq, q, q_stride, row, (size_t)nq));
+    SFM_RETURN_IF(upload_rows(ctx, dt, t, t_stride, row, (size_t)nt));
     SFM_RETURN_IF(sfm_knn2_dev(ctx, norm, dq, nq, row, dt, nt, row, d, di, dd));
     SFM_RETURN_IF(launch_ratio_compact(ctx, di, dd, nq, nt, ratio, dm, dc));
     int32_t count = 0;
     SFM_HIP_CHECK(ctx, hipMemcpyAsync(&count, dc, sizeof(int32_t), hipMemcpyDeviceToHost,
                                       ctx->stream));
     SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pinned_used = 0;
     if (count > 0)
         SFM_HIP_CHECK(ctx, hipMemcpy(out, dm, sizeof(sfm_dmatch) * (size_t)count,
                                      hipMemcpyDeviceToHost));
@@ -304,10 +302,8 @@ int sfm_robust_matches(sfm_ctx* ctx, int norm, const void* prev, int n_prev, siz
     int32_t* meta = c.take<int32_t>(8);  // pairs[2], counts[2], match count
     sfm_dmatch* dm = c.take<sfm_dmatch>((size_t)cap);
     SFM_HIP_CHECK(ctx, hipMemsetAsync(stack, 0, 2 * fstride, ctx->stream));
-    SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(stack, row, prev, prev_stride, row, n_prev,
-                                        hipMemcpyHostToDevice, ctx->stream));
-    SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(stack + fstride, row, curr, curr_stride, row, n_curr,
-                                        hipMemcpyHostToDevice, ctx->stream));
+    SFM_RETURN_IF(upload_rows(ctx, stack, prev, prev_stride, row, (size_t)n_prev));
+    SFM_RETURN_IF(upload_rows(ctx, stack + fstride, curr, curr_stride, row, (size_t)n_curr));
     const int32_t h_meta[8] = {0, 1, n_prev, n_curr, 0, 0, 0, 0};
     SFM_HIP_CHECK(ctx, hipMemcpyAsync(meta, h_meta, sizeof(h_meta), hipMemcpyHostToDevice,
                                       ctx->stream));
@@ -317,6 +313,7 @@ int sfm_robust_matches(sfm_ctx* ctx, int norm, const void* prev, int n_prev, siz
     SFM_HIP_CHECK(ctx, hipMemcpyAsync(&count, meta + 4, sizeof(int32_t), hipMemcpyDeviceToHost,
                                       ctx->stream));
     SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pinned_used = 0;
     if (count > cap) count = cap;
     if (count > 0)
         SFM_HIP_CHECK(ctx, hipMemcpy(out, dm, sizeof(sfm_dmatch) * (size_t)count,

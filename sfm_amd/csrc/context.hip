@@ -1,6 +1,7 @@
 // Context, error reporting and device buffers of libsfm_hip.so.
 #include "sfm_internal.h"
 
+#include <cstring>
 #include <new>
 
 namespace {
@@ -77,6 +78,40 @@ int staging(sfm_ctx* ctx, size_t bytes, void** out) {
     return SFM_OK;
 }
 
+int upload_rows(sfm_ctx* ctx, void* d_dst, const void* src, size_t src_stride, size_t row_bytes,
+                size_t rows) {
+    if (rows == 0 || row_bytes == 0) return SFM_OK;
+    const size_t bytes = rows * row_bytes;
+    if (src_stride == row_bytes || rows == 1) {
+        SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return SFM_OK;
+    }
+    if (ctx->pinned_used + bytes > ctx->pinned_bytes) {
+        // Earlier gathers may still be in flight from the old buffer.
+        SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->pinned_used = 0;
+        if (bytes > ctx->pinned_bytes) {
+            if (ctx->pinned) SFM_HIP_CHECK(ctx, hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_bytes = 0;
+            const size_t want = align_up(2 * bytes, size_t(1) << 20);
+            hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault);
+            if (e != hipSuccess) {
+                ctx->pinned = nullptr;
+                return set_error(ctx, SFM_E_NOMEM, "hipHostMalloc(%zu) failed: %s", want,
+                                 hipGetErrorString(e));
+            }
+            ctx->pinned_bytes = want;
+        }
+    }
+    char* dst = static_cast<char*>(ctx->pinned) + ctx->pinned_used;
+    ctx->pinned_used += align_up(bytes, 256);
+    const char* s = static_cast<const char*>(src);
+    for (size_t r = 0; r < rows; ++r) memcpy(dst + r * row_bytes, s + r * src_stride, row_bytes);
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_dst, dst, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return SFM_OK;
+}
+
 }  // namespace sfm
 
 static int create_common(int device, hipStream_t stream, bool own, sfm_ctx** out) {
@@ -133,6 +168,7 @@ void sfm_ctx_destroy(sfm_ctx* ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->staging) (void)hipFree(ctx->staging);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

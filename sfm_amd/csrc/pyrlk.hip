@@ -859,10 +859,8 @@ int sfm_pyrlk(sfm_ctx* ctx, const uint8_t* prev, const uint8_t* curr, int width,
     float* dout = c.take<float>(2 * (size_t)n);
     float* derr = c.take<float>((size_t)n);
     uint8_t* dst = c.take<uint8_t>((size_t)n);
-    SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(dp, width, prev, stride, width, height,
-                                        hipMemcpyHostToDevice, ctx->stream));
-    SFM_HIP_CHECK(ctx, hipMemcpy2DAsync(dc, width, curr, stride, width, height,
-                                        hipMemcpyHostToDevice, ctx->stream));
+    SFM_RETURN_IF(upload_rows(ctx, dp, prev, stride, (size_t)width, (size_t)height));
+    SFM_RETURN_IF(upload_rows(ctx, dc, curr, stride, (size_t)width, (size_t)height));
     SFM_HIP_CHECK(ctx, hipMemcpyAsync(dpts, prev_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice,
                                       ctx->stream));
     SFM_RETURN_IF(sfm_pyrlk_batch_dev(ctx, dp, dc, 1, img_bytes, width, height, (size_t)width, dpts,
@@ -875,6 +873,7 @@ int sfm_pyrlk(sfm_ctx* ctx, const uint8_t* prev, const uint8_t* curr, int width,
         SFM_HIP_CHECK(ctx, hipMemcpyAsync(err, derr, sizeof(float) * n, hipMemcpyDeviceToHost,
                                           ctx->stream));
     SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pinned_used = 0;
     return SFM_OK;
 }
 

@@ -45,6 +45,9 @@ struct sfm_ctx {
     size_t ws_bytes = 0;
     void* staging = nullptr;  // grow-only device buffer for the host-pointer entry points
     size_t staging_bytes = 0;
+    void* pinned = nullptr;   // grow-only page-locked host buffer for gathering strided rows
+    size_t pinned_bytes = 0;
+    size_t pinned_used = 0;   // bytes handed out since the stream was last idle
     int num_cus = 256;
     std::string err;
     bool profiling = false;
@@ -83,6 +86,12 @@ struct KernelTimer {
 int workspace(sfm_ctx* ctx, size_t bytes, void** out);
 // Second buffer used by host-pointer wrappers to stage inputs/outputs.
 int staging(sfm_ctx* ctx, size_t bytes, void** out);
+
+// One host-to-device transfer of `rows` rows of row_bytes bytes (src_stride apart in host
+// memory) into a dense device buffer, enqueued on the context's stream.  Strided sources are
+// gathered in page-locked memory first: a pitched copy would cost one transfer per row.
+int upload_rows(sfm_ctx* ctx, void* d_dst, const void* src, size_t src_stride, size_t row_bytes,
+                size_t rows);
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

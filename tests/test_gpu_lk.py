@@ -158,3 +158,22 @@ def test_pyrlk_batch_dev(ctx, oracle):
         np.testing.assert_array_equal(d_st[b].cpu().numpy(), ost)
         np.testing.assert_array_equal(d_out[b].cpu().numpy(), onxt)
         np.testing.assert_array_equal(d_err[b].cpu().numpy(), oerr)
+
+
+def test_pyrlk_host_region_of_interest(ctx, oracle):
+    """Host images that are views into wider buffers (row pitch > width), as a cv::Mat region
+    of interest is; two calls in a row so the second reuses the page-locked gather buffer."""
+    h, w = 150, 203
+    for seed in (31, 32):
+        p, c, pts = _pair(h, w, seed, 250)
+        wide_p = np.full((h, w + 37), 255, np.uint8)
+        wide_c = np.full((h, w + 37), 255, np.uint8)
+        wide_p[:, 5:5 + w] = p
+        wide_c[:, 5:5 + w] = c
+        vp, vc = wide_p[:, 5:5 + w], wide_c[:, 5:5 + w]
+        assert vp.strides[0] == w + 37
+        nxt, st, err = ctx.pyrlk(vp, vc, pts)
+        onxt, ost, oerr = oracle.pyrlk(p, c, pts, acc_exact=True)
+        np.testing.assert_array_equal(st, ost)
+        np.testing.assert_array_equal(nxt, onxt)
+        np.testing.assert_array_equal(err, oerr)

@@ -186,3 +186,21 @@ def test_match_pairs_batched(ctx, oracle):
         assert _tuples(m[p][: mc[p]]) == _tuples(want)
         total += len(want)
     assert total > 500
+
+
+def test_robust_matches_strided_rows(ctx, oracle):
+    """Descriptor rows that are views into wider host arrays go through the gather path."""
+    from sfm_amd import capi, synth
+
+    a, b = synth.descriptor_chain(2, 900, 32, seed=77)
+    wide_a = np.zeros((900, 50), np.uint8)
+    wide_b = np.zeros((900, 64), np.uint8)
+    wide_a[:, 3:35] = a
+    wide_b[:, 16:48] = b
+    for _ in range(2):
+        got = ctx.robust_matches(capi.NORM_HAMMING, wide_a[:, 3:35], wide_b[:, 16:48], 0.7)
+        want = oracle.robust_matches(capi.NORM_HAMMING, a, b, 0.7)
+        assert len(want) > 100 and got.tobytes() == want.tobytes()
+        fwd = ctx.ratio_matches(capi.NORM_HAMMING, wide_a[:, 3:35], wide_b[:, 16:48], 0.7)
+        idx, dist = oracle.knn2_hamming(a, b)
+        assert fwd.tobytes() == oracle.ratio_filter(idx, dist, 900, 0.7).tobytes()
