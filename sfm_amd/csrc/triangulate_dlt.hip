@@ -92,14 +92,25 @@ __device__ __forceinline__ bool rotate(double (&At)[4][4], double (&Vt)[4][4], d
     return true;
 }
 
+// The 4x4 system of cv::triangulatePoints.  kFused = false keeps OpenCV's operation order
+// (multiply, then subtract: what the Jacobi path, the faithful one, is compared bit-wise
+// against); the fast path fuses them.
+template <bool kFused>
 __device__ __forceinline__ void build_system(const TriArgs& a, double x1, double y1, double x2,
                                              double y2, double (&At)[4][4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        At[k][0] = x1 * a.P1[8 + k] - a.P1[k];
-        At[k][1] = y1 * a.P1[8 + k] - a.P1[4 + k];
-        At[k][2] = x2 * a.P2[8 + k] - a.P2[k];
-        At[k][3] = y2 * a.P2[8 + k] - a.P2[4 + k];
+        if (kFused) {
+            At[k][0] = fma(x1, a.P1[8 + k], -a.P1[k]);
+            At[k][1] = fma(y1, a.P1[8 + k], -a.P1[4 + k]);
+            At[k][2] = fma(x2, a.P2[8 + k], -a.P2[k]);
+            At[k][3] = fma(y2, a.P2[8 + k], -a.P2[4 + k]);
+        } else {
+            At[k][0] = x1 * a.P1[8 + k] - a.P1[k];
+            At[k][1] = y1 * a.P1[8 + k] - a.P1[4 + k];
+            At[k][2] = x2 * a.P2[8 + k] - a.P2[k];
+            At[k][3] = y2 * a.P2[8 + k] - a.P2[4 + k];
+        }
     }
 }
 
@@ -269,22 +280,120 @@ __device__ __forceinline__ bool null_vector_invit(const double (&At)[4][4], doub
     return done && !bad;
 }
 
+// Reciprocal of a positive, normal double: hardware estimate + two Newton steps
+// (about 1 ulp; the factorisation below does not need correctly rounded quotients).
+__device__ __forceinline__ double rcp_pos(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+// 1/sqrt(d) of a positive, normal double: hardware estimate + two Newton steps.
+__device__ __forceinline__ double rsqrt_pos(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    r = fma(fma(-h * r, r, 0.5), r, r);
+    r = fma(fma(-h * r, r, 0.5), r, r);
+    return r;
+}
+
+// Fixed-cost fast path: ONE factorisation M + e I = L D L^T (e = 1e-15 trace, so the
+// matrix is positive definite), three inverse-iteration solves with it, and an
+// a-posteriori acceptance test.  With a fixed shift the contamination of the iterate by
+// the other eigenvectors shrinks by the same factor q per solve, so the last two moves
+// d2 = |x2 - x1| (about the error of x1) and d3 = |x3 - x2| (about the error of x2) give
+// q = d3 / d2 and the error of x3 as d3 * q.  Points with d3^2 >= 1e-12 d2 (a small
+// eigenvalue gap: noisy or mismatched correspondences) are reported as not settled.
+__device__ __forceinline__ bool null_vector_invit3(const double (&At)[4][4], double (&v)[4]) {
+    double m[10];
+    {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i; j < 4; ++j) {
+                double s = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s = fma(At[i][r], At[j][r], s);
+                m[t++] = s;
+            }
+    }
+    const double trace = m[0] + m[4] + m[7] + m[9];
+    const double shift = trace * 1e-15;
+    const double tiny = trace * 1e-30 + 1e-300;
+    const double a00 = m[0] + shift, a11 = m[4] + shift, a22 = m[7] + shift, a33 = m[9] + shift;
+    const double a01 = m[1], a02 = m[2], a03 = m[3], a12 = m[5], a13 = m[6], a23 = m[8];
+    const double i0 = rcp_pos(a00 > tiny ? a00 : tiny);
+    const double l10 = a01 * i0, l20 = a02 * i0, l30 = a03 * i0;
+    const double d1 = fma(-l10, a01, a11);
+    const double i1 = rcp_pos(d1 > tiny ? d1 : tiny);
+    const double t21 = fma(-l20, a01, a12), t31 = fma(-l30, a01, a13);
+    const double l21 = t21 * i1, l31 = t31 * i1;
+    const double d2 = fma(-l21, t21, fma(-l20, a02, a22));
+    const double i2 = rcp_pos(d2 > tiny ? d2 : tiny);
+    const double t32 = fma(-l31, t21, fma(-l30, a02, a23));
+    const double l32 = t32 * i2;
+    const double d3 = fma(-l32, t32, fma(-l31, t31, fma(-l30, a03, a33)));
+    const double i3 = rcp_pos(d3 > tiny ? d3 : tiny);
+    const bool pivots_ok = a00 > tiny && d1 > tiny && d2 > tiny;
+
+    auto solve = [&](const double (&b)[4], double (&x)[4]) {
+        const double y0 = b[0];
+        const double y1 = fma(-l10, y0, b[1]);
+        const double y2 = fma(-l21, y1, fma(-l20, y0, b[2]));
+        const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, b[3])));
+        x[3] = y3 * i3;
+        x[2] = fma(-l32, x[3], y2 * i2);
+        x[1] = fma(-l31, x[3], fma(-l21, x[2], y1 * i1));
+        x[0] = fma(-l30, x[3], fma(-l20, x[2], fma(-l10, x[1], y0 * i0)));
+    };
+    // unit-norm iterate with the sign that makes it closest to `ref`; returns the move
+    auto settle = [&](double (&y)[4], const double (&ref)[4], bool& finite) {
+        const double n2 = fma(y[0], y[0], fma(y[1], y[1], fma(y[2], y[2], y[3] * y[3])));
+        finite = n2 > 0 && n2 < 1e300;
+        const double dot = fma(y[0], ref[0], fma(y[1], ref[1], fma(y[2], ref[2], y[3] * ref[3])));
+        double inv = rsqrt_pos(finite ? n2 : 1.0);
+        inv = dot < 0 ? -inv : inv;
+        double delta = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            y[k] *= inv;
+            delta = fmax(delta, fabs(y[k] - ref[k]));
+        }
+        return delta;
+    };
+
+    const double x0[4] = {0.1, 0.2, 0.9, 0.3};
+    double x1[4], x2[4], x3[4];
+    bool f1, f2, f3;
+    solve(x0, x1);
+    (void)settle(x1, x0, f1);
+    solve(x1, x2);
+    const double m2 = settle(x2, x1, f2);
+    solve(x2, x3);
+    const double m3 = settle(x3, x2, f3);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = x3[k];
+    return pivots_ok && f1 && f2 && f3 && (m3 <= 1e-13 || m3 * m3 < 1e-12 * m2);
+}
+
 // Division by w, reprojection, mask and colour for correspondence i (reconstruction.cpp:6-39).
 __device__ __forceinline__ void finish_point(const TriArgs& a, int i, const double (&v)[4], double x2,
                                              double y2) {
     const double scale = v[3] != 0 ? 1. / v[3] : 1.;
     const double Xw = v[0] * scale, Yw = v[1] * scale, Zw = v[2] * scale;
 
-    double x = a.R[0] * Xw + a.R[1] * Yw + a.R[2] * Zw + a.t[0];
-    double y = a.R[3] * Xw + a.R[4] * Yw + a.R[5] * Zw + a.t[1];
-    double z = a.R[6] * Xw + a.R[7] * Yw + a.R[8] * Zw + a.t[2];
+    double x = fma(a.R[0], Xw, fma(a.R[1], Yw, fma(a.R[2], Zw, a.t[0])));
+    double y = fma(a.R[3], Xw, fma(a.R[4], Yw, fma(a.R[5], Zw, a.t[1])));
+    double z = fma(a.R[6], Xw, fma(a.R[7], Yw, fma(a.R[8], Zw, a.t[2])));
     z = z != 0 ? 1. / z : 1.;
     x *= z;
     y *= z;
-    const double u = x * a.fx + a.cx, w = y * a.fy + a.cy;
+    const double u = fma(x, a.fx, a.cx), w = fma(y, a.fy, a.cy);
     const double du = u - x2, dv = w - y2;
-    const double e = sqrt(du * du + dv * dv);
-    const double depth = a.Pc2[0] * Xw + a.Pc2[1] * Yw + a.Pc2[2] * Zw + a.Pc2[3] * 1.0;
+    const double e = sqrt(fma(du, du, dv * dv));
+    const double depth = fma(a.Pc2[0], Xw, fma(a.Pc2[1], Yw, fma(a.Pc2[2], Zw, a.Pc2[3])));
 
     a.X[3 * (size_t)i] = Xw;
     a.X[3 * (size_t)i + 1] = Yw;
@@ -309,41 +418,64 @@ __global__ __launch_bounds__(256) void triangulate_dlt_kernel(TriArgs a) {
     const float2 p1 = live ? a.prev_pts[i] : make_float2(0.f, 0.f);
     const float2 p2 = live ? a.curr_pts[i] : make_float2(1.f, 1.f);
     double At[4][4], v[4];
-    build_system(a, p1.x, p1.y, p2.x, p2.y, At);
+    build_system<false>(a, p1.x, p1.y, p2.x, p2.y, At);
     null_vector_jacobi(At, v);
     if (live) finish_point(a, i, v, p2.x, p2.y);
 }
 
-// Fast path; unsettled points go to `list` (count in list_count[0]).
-__global__ __launch_bounds__(256) void triangulate_invit_kernel(TriArgs a, int* list_count, int* list) {
+// Deferred points are appended to one of kListBins lists (bin = workgroup index modulo
+// kListBins, bin b at list + b * bin_cap): one atomic per wave, spread over many addresses
+// (a single counter would serialise tens of thousands of atomics).
+constexpr int kListBins = 1024;
+
+// Fast path; unsettled points go to the lists.
+__global__ __launch_bounds__(256) void triangulate_invit_kernel(TriArgs a, int* bin_count, int* list,
+                                                                int bin_cap) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < a.n;
     const float2 p1 = live ? a.prev_pts[i] : make_float2(0.f, 0.f);
     const float2 p2 = live ? a.curr_pts[i] : make_float2(1.f, 1.f);
     double At[4][4], v[4];
-    build_system(a, p1.x, p1.y, p2.x, p2.y, At);
-    const bool ok = null_vector_invit(At, v);
-    if (!live) return;
-    if (ok)
-        finish_point(a, i, v, p2.x, p2.y);
-    else
-        list[atomicAdd(list_count, 1)] = i;
+    build_system<true>(a, p1.x, p1.y, p2.x, p2.y, At);
+    const bool ok = null_vector_invit3(At, v);
+    if (live && ok) finish_point(a, i, v, p2.x, p2.y);
+    const bool defer = live && !ok;
+    const unsigned long long votes = __ballot(defer);
+    if (votes) {
+        const int bin = blockIdx.x % kListBins;
+        const int lane = __lane_id();
+        const int leader = __ffsll((long long)votes) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(bin_count + bin, __popcll(votes));
+        base = __shfl(base, leader);
+        if (defer) list[(size_t)bin * bin_cap + base + __popcll(votes & ((1ull << lane) - 1))] = i;
+    }
 }
 
-// The listed points by one-sided Jacobi (grid-stride; exits at once when the list is empty).
-__global__ __launch_bounds__(256) void triangulate_list_kernel(TriArgs a, const int* list_count,
-                                                               const int* list) {
-    const int count = *list_count;
-    const int rounds = (count + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
-    for (int r = 0; r < rounds; ++r) {  // wave-uniform trip count: the Jacobi sweep loop votes
-        const int k = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+// The listed points, workgroup b taking bin b (exits at once when its bin is empty):
+// adaptively shifted inverse iteration, and one-sided Jacobi for the points that does not
+// settle either.
+__global__ __launch_bounds__(256) void triangulate_list_kernel(TriArgs a, const int* bin_count,
+                                                               const int* list, int bin_cap) {
+    const int count = bin_count[blockIdx.x];
+    const int* mine = list + (size_t)blockIdx.x * bin_cap;
+    for (int k0 = 0; k0 < count; k0 += blockDim.x) {  // workgroup-uniform trip count: the solvers vote
+        const int k = k0 + threadIdx.x;
         const bool live = k < count;
-        const int i = live ? list[k] : 0;
+        const int i = live ? mine[k] : mine[0];
         const float2 p1 = a.prev_pts[i];
         const float2 p2 = a.curr_pts[i];
         double At[4][4], v[4];
-        build_system(a, p1.x, p1.y, p2.x, p2.y, At);
-        null_vector_jacobi(At, v);
+        build_system<false>(a, p1.x, p1.y, p2.x, p2.y, At);
+        const bool ok = null_vector_invit(At, v);
+        if (__any(live && !ok)) {  // wave-uniform: the Jacobi sweep loop votes too
+            double vj[4];
+            null_vector_jacobi(At, vj);
+            if (!ok) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = vj[c];
+            }
+        }
         if (live) finish_point(a, i, v, p2.x, p2.y);
     }
 }
@@ -419,26 +551,28 @@ int sfm_triangulate_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
         SFM_HIP_CHECK(ctx, hipGetLastError());
         return SFM_OK;
     }
+    const int blocks = (n + 255) / 256;
+    const int bins = blocks < kListBins ? blocks : kListBins;
+    const int bin_cap = ((blocks + kListBins - 1) / kListBins) * 256;  // lanes that can land in one bin
     Carver sz(nullptr);
-    sz.take<int>(64);
-    sz.take<int>((size_t)n);
+    sz.take<int>(kListBins);
+    sz.take<int>((size_t)bins * bin_cap);
     void* ws;
     SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
     Carver c(ws);
-    int* list_count = c.take<int>(64);
-    int* list = c.take<int>((size_t)n);
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(list_count, 0, 256, ctx->stream));
+    int* bin_count = c.take<int>(kListBins);
+    int* list = c.take<int>((size_t)bins * bin_cap);
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(bin_count, 0, sizeof(int) * kListBins, ctx->stream));
     {
         KernelTimer timer(ctx, KID_TRIANGULATE_DLT);
-        hipLaunchKernelGGL(triangulate_invit_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
-                           a, list_count, list);
+        hipLaunchKernelGGL(triangulate_invit_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a,
+                           bin_count, list, bin_cap);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
     {
         KernelTimer timer(ctx, KID_TRIANGULATE_LIST);
-        const int blocks = n < 256 * 64 ? (n + 255) / 256 : 64;
-        hipLaunchKernelGGL(triangulate_list_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a,
-                           list_count, list);
+        hipLaunchKernelGGL(triangulate_list_kernel, dim3(bins), dim3(256), 0, ctx->stream, a,
+                           bin_count, list, bin_cap);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
     return SFM_OK;

@@ -63,6 +63,30 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned* out, unsigned seed)
                 if (OP == 36) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "v"(seed));
                 if (OP == 37) asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "v"(seed));
                 if (OP == 38) asm volatile("v_sad_u8 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "v"(seed));
+                if (OP == 39) asm volatile("v_min_f32 %0, %0, %1" : "+v"(f[i]) : "v"(fk));
+                if (OP == 40) asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[i]) : "v"(fk));
+                if (OP == 41) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(fk), "v"(f[(i + 1) & 7]));
+                if (OP == 42) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(f[i]) : "v"(fk));
+                if (OP == 43) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(f[i]) : "v"(fk));
+                if (OP == 44) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(v[i]));
+                if (OP == 45) asm volatile("v_xnor_b32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 46) asm volatile("v_not_b32 %0, %0" : "+v"(v[i]));
+                if (OP == 47) asm volatile("v_min_i32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 48) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 49) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 50) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(v[i]));
+                if (OP == 51) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 52) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "v"(seed));
+                if (OP == 53) asm volatile("v_subrev_u32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                // mixed streams: one full-rate and one half-rate instruction per step
+                if (OP == 54) asm volatile("v_xor_b32 %0, %0, %2\n\tv_bcnt_u32_b32 %1, %2, %1" : "+v"(v[i]), "+v"(f[i]) : "v"(k));
+                if (OP == 55) asm volatile("v_xor_b32 %0, %0, %2\n\tv_xor_b32 %1, %1, %2" : "+v"(v[i]), "+v"(f[i]) : "v"(k));
+                if (OP == 56) asm volatile("v_bcnt_u32_b32 %0, %2, %0\n\tv_bcnt_u32_b32 %1, %2, %1" : "+v"(v[i]), "+v"(f[i]) : "v"(k));
+                if (OP == 57) asm volatile("v_max_i32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 58) asm volatile("v_min_u16 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 59) asm volatile("v_add_u16 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+                if (OP == 60) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(v[i]) : "v"(k) : "vcc");
+                if (OP == 61) asm volatile("v_xor_b32 %0, %0, %2\n\tv_min_u32 %1, %2, %1" : "+v"(v[i]), "+v"(f[i]) : "v"(k));
             }
         }
     }
@@ -93,9 +117,36 @@ int run(const char* name, int waves_per_simd, unsigned* d_out) {
     return 0;
 }
 
-int main() {
+int main(int argc, char**) {
     unsigned* d_out;
     CHECK(hipMalloc(&d_out, 64));
+    const bool extra_only = argc > 1;
+    for (int w : {2, 4, 8}) {
+        run<39>("v_min_f32", w, d_out);
+        run<40>("v_max_f32", w, d_out);
+        run<41>("v_med3_f32", w, d_out);
+        run<42>("v_fmac_f32", w, d_out);
+        run<43>("v_sub_f32", w, d_out);
+        run<44>("v_lshrrev_b32", w, d_out);
+        run<45>("v_xnor_b32", w, d_out);
+        run<46>("v_not_b32", w, d_out);
+        run<47>("v_min_i32", w, d_out);
+        run<57>("v_max_i32", w, d_out);
+        run<48>("v_pk_min_u16", w, d_out);
+        run<49>("v_pk_add_u16", w, d_out);
+        run<58>("v_min_u16", w, d_out);
+        run<59>("v_add_u16", w, d_out);
+        run<50>("v_cvt_f32_u32", w, d_out);
+        run<51>("v_lshl_add_u32", w, d_out);
+        run<52>("v_or3_b32", w, d_out);
+        run<53>("v_subrev_u32", w, d_out);
+        run<60>("v_add_co_u32", w, d_out);
+        run<54>("xor+bcnt (2 instr)", w, d_out);
+        run<55>("xor+xor (2 instr)", w, d_out);
+        run<56>("bcnt+bcnt (2 instr)", w, d_out);
+        run<61>("xor+min_u32 (2 instr)", w, d_out);
+    }
+    if (extra_only) return 0;
     for (int w : {4, 8}) {
         run<14>("v_dot4_u32_u8", w, d_out);
         run<15>("v_dot2_u32_u16", w, d_out);
