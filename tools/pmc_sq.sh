@@ -1,0 +1,38 @@
+#!/bin/bash
+# SQ instruction / cycle counters of one bench workload (developer tool).
+# Usage: bash tools/pmc_sq.sh <workload> [extra bench args]
+set -u
+WL=${1:-framepair}
+shift || true
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/pmc_sq_$WL
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 150 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
+    --output-format csv -d "$OUT" -o $WL -- python3 $ROOT/bench.py --no-cpu-baseline --workload $WL --steps 2 --warmup 1 "$@" > "$OUT/run.log" 2>&1
+echo rc=$?
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, re, collections
+f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+dur = collections.defaultdict(lambda: [0.0, 0])
+seen = set()
+for r in csv.DictReader(open(f)):
+    m = re.search(r"([A-Za-z0-9_]+_kernel)", r["Kernel_Name"])
+    k = m.group(1) if m else r["Kernel_Name"][:40]
+    a = acc[k][r["Counter_Name"]]
+    a[0] += float(r["Counter_Value"]); a[1] += 1
+    key = (r["Dispatch_Id"])
+    if key not in seen:
+        seen.add(key)
+        d = dur[k]; d[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); d[1] += 1
+for k, c in acc.items():
+    if "rocclr" in k or "at::" in k or "elementwise" in k or "reduce" in k: continue
+    v = {n: a[0] / a[1] for n, a in c.items()}
+    w = v.get("SQ_WAVES", 0) or 1
+    us = dur[k][0] / dur[k][1] / 1e3
+    print(f"{k}: disp={dur[k][1]} dur={us:.1f}us waves={w:.0f} valu/wave={v.get('SQ_INSTS_VALU',0)/w:.0f} salu/wave={v.get('SQ_INSTS_SALU',0)/w:.0f} "
+          f"lds/wave={v.get('SQ_INSTS_LDS',0)/w:.0f} wave_cycles/wave={v.get('SQ_WAVE_CYCLES',0)/w:.0f} active_valu/wave={v.get('SQ_ACTIVE_INST_VALU',0)/w:.0f} "
+          f"wait_inst_any/wave={v.get('SQ_WAIT_INST_ANY',0)/w:.0f} busy_cycles={v.get('SQ_BUSY_CYCLES',0):.0f} gui_active={v.get('GRBM_GUI_ACTIVE',0):.0f} "
+          f"clock_GHz~{v.get('GRBM_GUI_ACTIVE',0)/ (us*1e3) if us else 0:.2f}")
+PY

@@ -86,6 +86,21 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned* out, unsigned seed)
                 if (OP == 58) asm volatile("v_min_u16 %0, %0, %1" : "+v"(v[i]) : "v"(k));
                 if (OP == 59) asm volatile("v_add_u16 %0, %0, %1" : "+v"(v[i]) : "v"(k));
                 if (OP == 60) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(v[i]) : "v"(k) : "vcc");
+                // run-length patterns of the Hamming inner loop: N xors then N popcount-accumulates
+                if (OP == 62 && (i & 3) == 0) asm volatile(
+                    "v_xor_b32 %0, %0, %4\n\tv_xor_b32 %1, %1, %4\n\tv_xor_b32 %2, %2, %4\n\tv_xor_b32 %3, %3, %4\n\t"
+                    "v_bcnt_u32_b32 %0, %4, %0\n\tv_bcnt_u32_b32 %1, %4, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\tv_bcnt_u32_b32 %3, %4, %3"
+                    : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]) : "v"(k));
+                if (OP == 63 && (i & 3) == 0) asm volatile(
+                    "v_xor_b32 %0, %0, %4\n\tv_xor_b32 %1, %1, %4\n\tv_xor_b32 %2, %2, %4\n\t"
+                    "v_bcnt_u32_b32 %0, %4, %0\n\tv_bcnt_u32_b32 %1, %4, %1\n\tv_bcnt_u32_b32 %2, %4, %2\n\tv_bcnt_u32_b32 %3, %4, %3\n\tv_xor_b32 %3, %3, %4"
+                    : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]) : "v"(k));
+                if (OP == 64 && i == 0) asm volatile(
+                    "v_xor_b32 %0, %0, %8\n\tv_xor_b32 %1, %1, %8\n\tv_xor_b32 %2, %2, %8\n\tv_xor_b32 %3, %3, %8\n\t"
+                    "v_xor_b32 %4, %4, %8\n\tv_xor_b32 %5, %5, %8\n\tv_xor_b32 %6, %6, %8\n\tv_xor_b32 %7, %7, %8\n\t"
+                    "v_bcnt_u32_b32 %0, %8, %0\n\tv_bcnt_u32_b32 %1, %8, %1\n\tv_bcnt_u32_b32 %2, %8, %2\n\tv_bcnt_u32_b32 %3, %8, %3\n\t"
+                    "v_bcnt_u32_b32 %4, %8, %4\n\tv_bcnt_u32_b32 %5, %8, %5\n\tv_bcnt_u32_b32 %6, %8, %6\n\tv_bcnt_u32_b32 %7, %8, %7"
+                    : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "v"(k));
                 if (OP == 61) asm volatile("v_xor_b32 %0, %0, %2\n\tv_min_u32 %1, %2, %1" : "+v"(v[i]), "+v"(f[i]) : "v"(k));
             }
         }
@@ -94,6 +109,50 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned* out, unsigned seed)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc += v[i] + (unsigned)f[i];
     if (acc == 0x12345678u) out[0] = acc;
+}
+
+// N xors followed by N popcount-accumulates, each on its own register (the shape of the
+// Hamming inner loop with all of a train row's xors issued before its popcounts).
+template <int N>
+__global__ __launch_bounds__(256) void pattern_kernel(unsigned* out, unsigned seed) {
+    unsigned t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = seed * (i + 1) + threadIdx.x;
+    unsigned k = seed | 1u;
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int u = 0; u < 32 / N; ++u) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(t[i]) : "v"(k));
+#pragma unroll
+            for (int i = 0; i < N; ++i) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(t[i]) : "v"(k));
+        }
+    }
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc += t[i];
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <int N>
+int run_pattern(int waves_per_simd, unsigned* d_out) {
+    const int blocks = 256 * waves_per_simd;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    pattern_kernel<N><<<blocks, 256>>>(d_out, 7);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) pattern_kernel<N><<<blocks, 256>>>(d_out, 7);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double pairs = 5.0 * blocks * 4 * (double)ITERS * 32;  // (xor, bcnt) pairs per wave
+    const double per_simd_per_s = pairs / (ms * 1e-3) / 1024.0;
+    printf("%dxor+%dbcnt runs  waves/SIMD=%d  %.3f ms  %.2f cycles per (xor,bcnt) pair @2.4GHz\n", N, N,
+           waves_per_simd, ms / 5, 2.4e9 / per_simd_per_s);
+    return 0;
 }
 
 template <int OP>
@@ -145,6 +204,16 @@ int main(int argc, char**) {
         run<55>("xor+xor (2 instr)", w, d_out);
         run<56>("bcnt+bcnt (2 instr)", w, d_out);
         run<61>("xor+min_u32 (2 instr)", w, d_out);
+        run<62>("4xor+4bcnt (per pair x4)", w, d_out);
+        run<63>("3xor+4bcnt+1xor (per pair x4)", w, d_out);
+        run<64>("8xor+8bcnt (per pair x8)", w, d_out);
+    }
+    for (int w : {2, 5, 8}) {
+        run_pattern<1>(w, d_out);
+        run_pattern<4>(w, d_out);
+        run_pattern<8>(w, d_out);
+        run_pattern<16>(w, d_out);
+        run_pattern<32>(w, d_out);
     }
     if (extra_only) return 0;
     for (int w : {4, 8}) {
