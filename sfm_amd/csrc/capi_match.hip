@@ -1,6 +1,7 @@
 // extern "C" entry points of the descriptor-matching stage (see include/sfm_hip.h).
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <vector>
 
 #include "sfm_internal.h"
@@ -25,7 +26,7 @@ constexpr int kMaxTrainRows = 1 << 18;
 constexpr int kMaxHammingBytes = 256;
 // Pairs handled per launch sequence: bounds the key workspace (2 problems per
 // pair, 8 bytes per query row and split).
-constexpr int kPairChunk = 4096;
+constexpr int kPairChunk = 1024;
 constexpr int kL2PairChunk = 256;  // float candidates take 16 bytes per query row and split
 
 int check_common(sfm_ctx* ctx, int norm, int n_a, int n_b, int d) {
@@ -46,6 +47,16 @@ bool is_packed(const void* p, size_t stride, int d, int row_words) {
     return d == row_words * 4 && stride == (size_t)d && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
 }
 
+// Whether the one-pass pair kernel handles this row width.  SFM_PAIR_KERNEL=0 selects the
+// two-direction path for every width (a debugging and measurement aid).
+bool use_pair_kernel(int row_words) {
+    static const bool enabled = [] {
+        const char* e = getenv("SFM_PAIR_KERNEL");
+        return !(e && e[0] == '0');
+    }();
+    return enabled && hamming_pair_block_rows(row_words) > 0;
+}
+
 // Hamming robust matching over frames already packed to plan.row_words words per
 // row.  Workspace is carved from `c`.
 int hamming_pairs_packed(sfm_ctx* ctx, const KnnPlan& plan, const void* packed, size_t frame_stride,
@@ -53,6 +64,18 @@ int hamming_pairs_packed(sfm_ctx* ctx, const KnnPlan& plan, const void* packed, 
                          int n_pairs, float ratio, sfm_dmatch* d_matches, int cap,
                          int32_t* d_match_counts, Carver& c) {
     const size_t nprob = 2 * (size_t)n_pairs;
+    if (use_pair_kernel(plan.row_words)) {
+        const PairPlan pp = make_pair_plan(ctx, plan.row_words, plan.rows_max, n_pairs);
+        uint32_t* keys_row = c.take<uint32_t>((size_t)n_pairs * pp.splits * pp.rows_max * 2);
+        uint32_t* keys_col = c.take<uint32_t>((size_t)n_pairs * pp.qblocks * pp.rows_max * 2);
+        int32_t* best = c.take<int32_t>(nprob * plan.rows_max);
+        float* best_dist = c.take<float>(nprob * plan.rows_max);
+        SFM_RETURN_IF(launch_hamming_pairs(ctx, pp, packed, frame_stride, rows_uniform, d_counts,
+                                           d_pairs, n_pairs, keys_row, keys_col));
+        return launch_ratio_cross_pairs(ctx, pp, keys_row, keys_col, d_counts, rows_uniform, d_pairs,
+                                        n_pairs, ratio, best, best_dist, d_matches, cap,
+                                        d_match_counts);
+    }
     uint32_t* keys = c.take<uint32_t>(nprob * plan.splits * plan.rows_max * 2);
     int32_t* best = c.take<int32_t>(nprob * plan.rows_max);
     float* best_dist = c.take<float>(nprob * plan.rows_max);
@@ -68,10 +91,16 @@ int hamming_pairs_packed(sfm_ctx* ctx, const KnnPlan& plan, const void* packed, 
                               n_pairs, ratio, best, best_dist, d_matches, cap, d_match_counts);
 }
 
-size_t hamming_pairs_bytes(const KnnPlan& plan, int n_pairs) {
+size_t hamming_pairs_bytes(const sfm_ctx* ctx, const KnnPlan& plan, int n_pairs) {
     Carver c(nullptr);
     const size_t nprob = 2 * (size_t)n_pairs;
-    c.take<uint32_t>(nprob * plan.splits * plan.rows_max * 2);
+    if (use_pair_kernel(plan.row_words)) {
+        const PairPlan pp = make_pair_plan(ctx, plan.row_words, plan.rows_max, n_pairs);
+        c.take<uint32_t>((size_t)n_pairs * pp.splits * pp.rows_max * 2);
+        c.take<uint32_t>((size_t)n_pairs * pp.qblocks * pp.rows_max * 2);
+    } else {
+        c.take<uint32_t>(nprob * plan.splits * plan.rows_max * 2);
+    }
     c.take<int32_t>(nprob * plan.rows_max);
     c.take<float>(nprob * plan.rows_max);
     return c.total();
@@ -219,7 +248,7 @@ size_t sfm_match_pairs_workspace(int norm, int n_frames, int rows_per_frame, int
     sfm_ctx fake;
     KnnPlan plan = make_knn_plan(&fake, norm, d, rows_per_frame, rows_per_frame, 2 * chunk);
     const bool packed = d == plan.row_words * 4;
-    return hamming_pairs_bytes(plan, chunk) +
+    return hamming_pairs_bytes(&fake, plan, chunk) +
            (packed ? 0 : align_up((size_t)n_frames * rows_per_frame * plan.row_words * 4, 256));
 }
 
@@ -250,7 +279,7 @@ int sfm_match_pairs_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames
     if (!packed) sz.take<uint8_t>((size_t)n_frames * rows_per_frame * row_bytes);
     const size_t fixed = sz.total();
     void* ws;
-    SFM_RETURN_IF(workspace(ctx, fixed + hamming_pairs_bytes(plan, chunk), &ws));
+    SFM_RETURN_IF(workspace(ctx, fixed + hamming_pairs_bytes(ctx, plan, chunk), &ws));
     Carver c(ws);
     const void* base = d_desc;
     size_t fstride = frame_stride;

@@ -207,7 +207,7 @@ int sfm_profile_kernel_count(void) { return sfm::KID_COUNT; }
 
 const char* sfm_profile_kernel_name(int kernel_id) {
     static const char* names[sfm::KID_COUNT] = {
-        "hamming_knn2_kernel", "ratio_cross_kernel", "merge_ratio_kernel", "knn_finalize_kernel", "pack_rows_kernel",
+        "hamming_knn2_kernel", "hamming_pair_kernel", "ratio_cross_kernel", "merge_ratio_kernel", "knn_finalize_kernel", "pack_rows_kernel",
         "ratio_compact_kernel", "l2_candidates_kernel", "l2_rescore_kernel", "l2_pack_kernel",
         "lk_pad_level0_kernel", "lk_pyr_down_kernel", "lk_scharr_kernel", "lk_track_kernel",
         "triangulate_dlt_kernel", "triangulate_list_kernel"};

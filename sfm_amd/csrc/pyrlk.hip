@@ -153,33 +153,54 @@ __global__ void lk_pyr_down_kernel(LkGeom g, int level, uint8_t* __restrict__ py
     }
 }
 
-// Scharr derivative of the previous image at one level; zero in the border.
-__global__ void lk_scharr_kernel(LkGeom g, int level, const uint8_t* __restrict__ pyr_prev,
+// Scharr derivative of the previous image, all levels in one launch (blockIdx.y = level,
+// blockIdx.z = pair); zero in the border.  One thread writes four adjacent pixels (16 bytes)
+// from three aligned dwords of each of the three source rows.
+__global__ void lk_scharr_kernel(LkGeom g, const uint8_t* __restrict__ pyr_prev,
                                  uint32_t* __restrict__ deriv) {
-    const int pair = blockIdx.z;
+    const int level = blockIdx.y, pair = blockIdx.z;
     const uint8_t* src = pyr_prev + (size_t)pair * g.block + g.img_off[level];
     uint32_t* dst = deriv + (size_t)pair * g.block + g.img_off[level];
     const int S = g.stride[level], w = g.w[level], h = g.h[level];
-    const int y = (int)blockIdx.y - g.bh;
-    if (y >= h + g.bh) return;
-    uint32_t* drow = dst + (ptrdiff_t)y * S - g.bw;
-    const bool yin = y >= 0 && y < h;
-    for (int xi = blockIdx.x * blockDim.x + threadIdx.x; xi < S; xi += gridDim.x * blockDim.x) {
-        const int x = xi - g.bw;
-        uint32_t out = 0;
-        if (yin && x >= 0 && x < w) {
-            const uint8_t* r0 = src + (ptrdiff_t)(y - 1) * S + x;
-            const uint8_t* r1 = r0 + S;
-            const uint8_t* r2 = r1 + S;
-            // vertical pass at columns x-1, x, x+1 (lkpyramid.cpp calcSharrDeriv)
-            const int s_m = (r0[-1] + r2[-1]) * 3 + r1[-1] * 10, d_m = r2[-1] - r0[-1];
-            const int d_0 = r2[0] - r0[0];
-            const int s_p = (r0[1] + r2[1]) * 3 + r1[1] * 10, d_p = r2[1] - r0[1];
-            const int ix = s_p - s_m;
-            const int iy = (d_p + d_m) * 3 + d_0 * 10;
-            out = ((uint32_t)ix & 0xFFFFu) | ((uint32_t)iy << 16);
+    const int per_row = S / 4, total = per_row * (h + 2 * g.bh);
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int y = t / per_row - g.bh, xi = (t % per_row) * 4;
+        const int x0 = xi - g.bw;  // image column of the first of the four pixels
+        uint32_t out[4] = {0, 0, 0, 0};
+        if (y >= 0 && y < h && x0 + 3 >= 0 && x0 < w) {
+            // padded columns xi-1 .. xi+4 of rows y-1, y, y+1 (lkpyramid.cpp calcSharrDeriv:
+            // vertical pass first, then the horizontal one)
+            int sv[6], dv[6];
+            const uint8_t* r1 = src + (ptrdiff_t)y * S + x0;
+            uint32_t px[3][6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const uint8_t* row = r1 + (ptrdiff_t)(r - 1) * S;
+                const uint32_t a = xi >= 4 ? *reinterpret_cast<const uint32_t*>(row - 4) : 0u;
+                const uint32_t b = *reinterpret_cast<const uint32_t*>(row);
+                const uint32_t c = xi + 4 < S ? *reinterpret_cast<const uint32_t*>(row + 4) : 0u;
+                px[r][0] = a >> 24;
+                px[r][1] = b & 0xFF;
+                px[r][2] = (b >> 8) & 0xFF;
+                px[r][3] = (b >> 16) & 0xFF;
+                px[r][4] = b >> 24;
+                px[r][5] = c & 0xFF;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                sv[k] = (int)(px[0][k] + px[2][k]) * 3 + (int)px[1][k] * 10;
+                dv[k] = (int)px[2][k] - (int)px[0][k];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ix = sv[i + 2] - sv[i];
+                const int iy = (dv[i + 2] + dv[i]) * 3 + dv[i + 1] * 10;
+                const bool in = (unsigned)(x0 + i) < (unsigned)w;
+                out[i] = in ? (((uint32_t)ix & 0xFFFFu) | ((uint32_t)iy << 16)) : 0u;
+            }
         }
-        drow[xi] = out;
+        uint32_t* drow = dst + (ptrdiff_t)y * S - g.bw;
+        *reinterpret_cast<uint4*>(drow + xi) = make_uint4(out[0], out[1], out[2], out[3]);
     }
 }
 
@@ -784,12 +805,11 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
                            bufs.pyr_curr);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
-    for (int l = 0; l <= g.levels; ++l) {
-        const int S = g.stride[l];
-        const dim3 grid((S + 255) / 256, g.h[l] + 2 * g.bh, n_pairs);
+    {
+        const int S = g.stride[0];
+        const dim3 grid(((S / 4) * (g.h[0] + 2 * g.bh) + 255) / 256, g.levels + 1, n_pairs);
         KernelTimer timer(ctx, KID_LK_SCHARR);
-        hipLaunchKernelGGL(lk_scharr_kernel, grid, blk, 0, ctx->stream, g, l, bufs.pyr_prev,
-                           bufs.deriv);
+        hipLaunchKernelGGL(lk_scharr_kernel, grid, blk, 0, ctx->stream, g, bufs.pyr_prev, bufs.deriv);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
 

@@ -18,10 +18,15 @@ constexpr int kIdxBits = 18;
 constexpr int kThreads = 1024;
 
 struct CrossArgs {
-    const uint2* keys;        // Hamming: per-split packed keys; nullptr -> use knn_idx/knn_dist
+    // Hamming: partial packed keys per direction (0: prev -> curr, 1: curr -> prev), pair p at
+    // keys_dir[d] + p * pair_stride_dir[d], part k at + k * rows_max; keys_dir[0] == nullptr ->
+    // use knn_idx / knn_dist
+    const uint2* keys_dir[2];
+    size_t pair_stride_dir[2];
+    int parts_dir[2];
+    int col_block_rows;       // > 0: direction 1 has one part per col_block_rows rows of prev
     const int32_t* knn_idx;   // [2*n_pairs][rows_max][2]
     const float* knn_dist;
-    int splits;
     int rows_max;
     const int32_t* counts;
     int n_prev_uniform;
@@ -55,10 +60,12 @@ __global__ __launch_bounds__(256) void merge_ratio_kernel(CrossArgs a) {
     const uint32_t mask = (1u << kIdxBits) - 1;
     float d0, d1;
     int32_t i0, i1;
-    if (a.keys) {
-        const uint2* keys = a.keys + (size_t)problem * a.splits * (size_t)a.rows_max;
+    if (a.keys_dir[0]) {
+        const uint2* keys = a.keys_dir[dir] + (size_t)pair * a.pair_stride_dir[dir];
+        const int parts = dir && a.col_block_rows > 0 ? (nt + a.col_block_rows - 1) / a.col_block_rows
+                                                      : a.parts_dir[dir];
         uint32_t m1 = kNoKey, m2 = kNoKey;
-        for (int s = 0; s < a.splits; ++s) {
+        for (int s = 0; s < parts; ++s) {
             const uint2 k = keys[(size_t)s * a.rows_max + q];
             m2 = med3_u32(m1, m2, k.x);
             m1 = min(m1, k.x);
@@ -186,12 +193,51 @@ int launch_ratio_cross(sfm_ctx* ctx, const KnnPlan& plan, const uint32_t* d_keys
                        int32_t* d_match_counts) {
     if (n_pairs <= 0) return SFM_OK;
     CrossArgs a{};
-    a.keys = reinterpret_cast<const uint2*>(d_keys);
-    a.splits = plan.splits;
+    a.keys_dir[0] = reinterpret_cast<const uint2*>(d_keys);
+    a.keys_dir[1] = a.keys_dir[0] + (size_t)plan.splits * plan.rows_max;
+    a.pair_stride_dir[0] = a.pair_stride_dir[1] = 2 * (size_t)plan.splits * plan.rows_max;
+    a.parts_dir[0] = a.parts_dir[1] = plan.splits;
     a.rows_max = plan.rows_max;
     a.counts = d_counts;
     a.n_prev_uniform = rows_uniform_prev;
     a.n_curr_uniform = rows_uniform_curr;
+    a.pairs = d_pairs;
+    a.ratio = ratio;
+    a.best = d_best;
+    a.best_dist = d_best_dist;
+    a.matches = d_matches;
+    a.cap = cap;
+    a.match_counts = d_match_counts;
+    {
+        KernelTimer timer(ctx, KID_MERGE_RATIO);
+        hipLaunchKernelGGL(merge_ratio_kernel, dim3((a.rows_max + 255) / 256, 2 * n_pairs), dim3(256),
+                           0, ctx->stream, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    KernelTimer timer(ctx, KID_RATIO_CROSS);
+    hipLaunchKernelGGL(ratio_cross_kernel, dim3(n_pairs), dim3(kThreads), 0, ctx->stream, a);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+int launch_ratio_cross_pairs(sfm_ctx* ctx, const PairPlan& plan, const uint32_t* d_keys_row,
+                             const uint32_t* d_keys_col, const int32_t* d_counts, int rows_uniform,
+                             const int32_t* d_pairs, int n_pairs, float ratio, int32_t* d_best,
+                             float* d_best_dist, sfm_dmatch* d_matches, int cap,
+                             int32_t* d_match_counts) {
+    if (n_pairs <= 0) return SFM_OK;
+    CrossArgs a{};
+    a.keys_dir[0] = reinterpret_cast<const uint2*>(d_keys_row);
+    a.keys_dir[1] = reinterpret_cast<const uint2*>(d_keys_col);
+    a.pair_stride_dir[0] = (size_t)plan.splits * plan.rows_max;
+    a.pair_stride_dir[1] = (size_t)plan.qblocks * plan.rows_max;
+    a.parts_dir[0] = plan.splits;
+    a.parts_dir[1] = plan.qblocks;
+    a.col_block_rows = hamming_pair_block_rows(plan.row_words);
+    a.rows_max = plan.rows_max;
+    a.counts = d_counts;
+    a.n_prev_uniform = rows_uniform;
+    a.n_curr_uniform = rows_uniform;
     a.pairs = d_pairs;
     a.ratio = ratio;
     a.best = d_best;
@@ -218,10 +264,8 @@ int launch_ratio_cross_knn(sfm_ctx* ctx, const int32_t* d_knn_idx, const float* 
                            int32_t* d_match_counts) {
     if (n_pairs <= 0) return SFM_OK;
     CrossArgs a{};
-    a.keys = nullptr;
     a.knn_idx = d_knn_idx;
     a.knn_dist = d_knn_dist;
-    a.splits = 1;
     a.rows_max = rows_max;
     a.counts = d_counts;
     a.n_prev_uniform = rows_uniform;

@@ -15,6 +15,7 @@ namespace sfm {
 // Kernel families, for the optional per-kernel event timing (sfm_ctx_set_profiling).
 enum KernelId {
     KID_HAMMING_KNN2 = 0,
+    KID_HAMMING_PAIR,
     KID_RATIO_CROSS,
     KID_MERGE_RATIO,
     KID_KNN_FINALIZE,
@@ -146,6 +147,29 @@ struct KnnBatch {
 // Writes partial top-2 keys: keys[problem][split][row][2] (uint32 for Hamming,
 // uint64 for L2 candidates, see the kernels).
 int launch_hamming_knn2(sfm_ctx* ctx, const KnnPlan& plan, const KnnBatch& b, uint32_t* d_keys);
+
+// Both directions of every pair from one pass over the distance matrix (hamming_pair.hip).
+struct PairPlan {
+    int row_words;
+    int rows_max;
+    int qblocks;            // workgroups along the prev rows
+    int splits;             // workgroups along the curr rows
+    int batches_per_split;
+};
+// Rows of prev one workgroup owns, or 0 when no pair kernel exists for that row width.
+int hamming_pair_block_rows(int row_words);
+PairPlan make_pair_plan(const sfm_ctx* ctx, int row_words, int rows_max, int n_pairs);
+// keys_row: [pair][split][rows_max][2] (prev -> curr), keys_col: [pair][qblock][rows_max][2]
+// (curr -> prev; only the qblocks that hold rows of prev are written).
+int launch_hamming_pairs(sfm_ctx* ctx, const PairPlan& plan, const void* packed, size_t frame_stride,
+                         int rows_uniform, const int32_t* d_counts, const int32_t* d_pairs,
+                         int n_pairs, uint32_t* d_keys_row, uint32_t* d_keys_col);
+// Ratio test, cross-check and compaction over the partial keys of launch_hamming_pairs.
+int launch_ratio_cross_pairs(sfm_ctx* ctx, const PairPlan& plan, const uint32_t* d_keys_row,
+                             const uint32_t* d_keys_col, const int32_t* d_counts, int rows_uniform,
+                             const int32_t* d_pairs, int n_pairs, float ratio, int32_t* d_best,
+                             float* d_best_dist, sfm_dmatch* d_matches, int cap,
+                             int32_t* d_match_counts);
 
 // Merges the splits of a single problem and writes idx/dist [nq][2].
 int launch_knn_finalize(sfm_ctx* ctx, const KnnPlan& plan, const uint32_t* d_keys, int nq,
