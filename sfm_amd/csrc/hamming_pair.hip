@@ -30,7 +30,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
-constexpr int kIdxBits = 18;
+constexpr int kIdxBits = 18;  // also the literal in make_key
 
 struct PairArgs {
     const uint32_t* base;      // packed descriptor frames
@@ -50,6 +50,23 @@ struct PairArgs {
 __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// popcount(x) + acc in one instruction.  Written as asm because the compiler otherwise
+// re-associates the eight-term sum into v_bcnt(x, 0) + v_add3 trees: four more
+// instructions per distance.
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+// (d << 18) | idx in one instruction (the compiler shares the shift between the row key
+// and the column key and then needs three).
+__device__ __forceinline__ uint32_t make_key(uint32_t d, uint32_t idx) {
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, 18, %2" : "=v"(r) : "v"(d), "v"(idx));
     return r;
 }
 
@@ -176,11 +193,11 @@ __global__ __launch_bounds__(kBlock) void hamming_pair_kernel(PairArgs a) {
                     const uint32_t tinv = kMasked ? ((int)tidx < n_curr ? 0u : kNoKey) : 0u;
 #pragma unroll
                     for (int j = 0; j < Q; ++j) {
-                        uint32_t dsum = 0;
+                        uint32_t dsum = __builtin_popcount(qr[j][0] ^ tr[0]);
 #pragma unroll
-                        for (int w = 0; w < W; ++w) dsum += __builtin_popcount(qr[j][w] ^ tr[w]);
-                        uint32_t krow = (dsum << kIdxBits) | tidx;
-                        uint32_t kcol = (dsum << kIdxBits) | qidx[j];
+                        for (int w = 1; w < W; ++w) dsum = bcnt_acc(qr[j][w] ^ tr[w], dsum);
+                        uint32_t krow = make_key(dsum, tidx);
+                        uint32_t kcol = make_key(dsum, qidx[j]);
                         if (kMasked) {
                             krow |= tinv;      // a curr row past the end never becomes a neighbour
                             kcol |= qinv[j];   // nor does a prev row past the end
