@@ -362,6 +362,11 @@ static int64_t lk_track_point(const lk_level* I, const lk_level* J, int level, i
     return iters;
 }
 
+/* Optional per (level, point) iteration counts for studying the distribution: when set, the
+ * next orc_pyrlk calls store their counts at buf[level * n + i]. */
+static int32_t* g_iter_buf = NULL;
+void orc_lk_set_iter_buffer(int32_t* buf) { g_iter_buf = buf; }
+
 void orc_pyrlk(const uint8_t* prev, const uint8_t* curr, int w, int h, size_t stride,
                const float* prev_pts, int n, int win_w, int win_h, int max_level, int crit_type,
                int max_count, double epsilon, double min_eig_threshold, float max_error,
@@ -405,11 +410,14 @@ void orc_pyrlk(const uint8_t* prev, const uint8_t* curr, int w, int h, size_t st
             int16_t* IWin = (int16_t*)malloc(sizeof(int16_t) * 3 * (size_t)win_w * (size_t)win_h);
             int16_t* dIWin = IWin + (size_t)win_w * (size_t)win_h;
 #pragma omp for schedule(dynamic, 64)
-            for (int i = 0; i < n; ++i)
-                total_iters += lk_track_point(&P[level], &N[level], level, levels, win_w, win_h,
-                                              max_count, epsilon, (float)min_eig_threshold,
-                                              prev_pts + 2 * i, curr_pts + 2 * i, status + i,
-                                              err + i, acc_exact, IWin, dIWin);
+            for (int i = 0; i < n; ++i) {
+                const int64_t it = lk_track_point(&P[level], &N[level], level, levels, win_w, win_h,
+                                                  max_count, epsilon, (float)min_eig_threshold,
+                                                  prev_pts + 2 * i, curr_pts + 2 * i, status + i,
+                                                  err + i, acc_exact, IWin, dIWin);
+                total_iters += it;
+                if (g_iter_buf) g_iter_buf[(size_t)level * n + i] = (int32_t)it;
+            }
             free(IWin);
         }
     }

@@ -95,6 +95,9 @@ int orc_lk_num_levels(int w, int h, int win_w, int win_h, int max_level);
  * acc_exact != 0 accumulates the normal-equation sums in int64 (exact)
  * instead of OpenCV's float accumulators; everything else is identical.
  * iters_out (nullable) receives the total number of LK iterations run. */
+/* Study aid: per (level, point) iteration counts of the following orc_pyrlk calls go to
+ * buf[level * n + i]; NULL switches it off. */
+void orc_lk_set_iter_buffer(int32_t* buf);
 void orc_pyrlk(const uint8_t* prev, const uint8_t* curr, int w, int h,
                size_t stride, const float* prev_pts, int n, int win_w,
                int win_h, int max_level, int crit_type, int max_count,

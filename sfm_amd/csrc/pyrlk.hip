@@ -342,17 +342,21 @@ __device__ __forceinline__ uint2 load_u8x8(const uint8_t* p) {
     return v;
 }
 
-// (b[J] | b[J+1] << 16) out of the eight bytes {v.x, v.y}: the u16 pair of two
-// horizontally adjacent pixels.
+// (a[J] | b[J] << 16): the u16 pair of two vertically adjacent pixels, column J of the
+// eight bytes a = {a.x, a.y} (row y) and b (row y + 1).
 template <int J>
-__device__ __forceinline__ uint32_t px_pair(uint2 v) {
-    constexpr uint32_t sel = (uint32_t)J | (0x0Cu << 8) | ((uint32_t)(J + 1) << 16) | (0x0Cu << 24);
-    return __builtin_amdgcn_perm(v.y, v.x, sel);
+__device__ __forceinline__ uint32_t col_pair(uint2 a, uint2 b) {
+    constexpr uint32_t sel = (uint32_t)(J & 3) | (0x0Cu << 8) | ((uint32_t)(4 + (J & 3)) << 16) | (0x0Cu << 24);
+    return __builtin_amdgcn_perm(J < 4 ? b.x : b.y, J < 4 ? a.x : a.y, sel);
 }
 
+// OpenCV's four fixed-point bilinear weights, paired by COLUMN of the 2x2 footprint: one
+// pair multiplies the pixels (x, y), (x, y+1), the other (x+1, y), (x+1, y+1).  A column
+// pair of pixels then serves two neighbouring output pixels (as the right column of one and
+// the left column of the next), which halves the byte shuffles against pairing by row.
 struct Weights {
-    uint32_t w0;  // iw00 | iw01 << 16 (row y)
-    uint32_t w1;  // iw10 | iw11 << 16 (row y + 1)
+    uint32_t wl;  // iw00 | iw10 << 16
+    uint32_t wr;  // iw01 | iw11 << 16
 };
 
 __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
@@ -361,41 +365,34 @@ __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
     const int w10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
     const int w11 = (1 << W_BITS) - w00 - w01 - w10;
     Weights w;
-    w.w0 = (uint32_t)w00 | ((uint32_t)w01 << 16);
-    w.w1 = (uint32_t)w10 | ((uint32_t)w11 << 16);  // w11 may be negative: it sits in the high half
+    w.wl = (uint32_t)w00 | ((uint32_t)w10 << 16);
+    w.wr = (uint32_t)w01 | ((uint32_t)w11 << 16);  // w11 may be -1: it sits in the high half
     return w;
-}
-
-// Interpolated window pixel with 5 fractional bits, CV_DESCALE(..., W_BITS-5):
-// two 16-bit dot products (row y and row y+1) on pixel pairs and weight pairs.
-// Signed: iw11 = 2^14 - (the three rounded weights) can be -1.
-__device__ __forceinline__ int interp_px(uint32_t pair0, uint32_t pair1, const Weights& w) {
-    int acc = 1 << (W_BITS - 5 - 1);
-    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, pair0),
-                                 __builtin_bit_cast(short2_t, w.w0), acc, false);
-    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, pair1),
-                                 __builtin_bit_cast(short2_t, w.w1), acc, false);
-    return acc >> (W_BITS - 5);
-}
-
-// Interpolated derivative, CV_DESCALE(..., W_BITS), on signed 16-bit pairs.
-__device__ __forceinline__ int interp_deriv(uint32_t pair0, uint32_t pair1, const Weights& w) {
-    int acc = 1 << (W_BITS - 1);
-    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, pair0),
-                                 __builtin_bit_cast(short2_t, w.w0), acc, false);
-    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, pair1),
-                                 __builtin_bit_cast(short2_t, w.w1), acc, false);
-    return acc >> W_BITS;
-}
-
-// (lo16(a) | lo16(b) << 16): two 16-bit values side by side
-__device__ __forceinline__ uint32_t pack16(int a, int b) {
-    return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x05040100u);
 }
 
 __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), c,
                                   false);
+}
+
+// Signed 16-bit dot product plus a constant that travels in an SGPR.  (The compiler's
+// choice for a constant accumulator is v_mov + v_dot2c: one more vector instruction per
+// interpolated value.)
+__device__ __forceinline__ int sdot2_k(uint32_t a, uint32_t b, int k) {
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+
+// Weighted sum of one 2x2 footprint from its two column pairs, rounding constant included.
+// Signed: iw11 = 2^14 - (the three rounded weights) can be -1.
+__device__ __forceinline__ int footprint(uint32_t left, uint32_t right, const Weights& w, int round) {
+    return sdot2(right, w.wr, sdot2_k(left, w.wl, round));
+}
+
+// (lo16(a) | lo16(b) << 16): two 16-bit values side by side
+__device__ __forceinline__ uint32_t pack16(int a, int b) {
+    return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x05040100u);
 }
 
 __device__ __forceinline__ int mad24(int a, int b, int c) {
@@ -419,20 +416,29 @@ struct SlotWin {
     int m6;
 };
 
-// Interpolated J window of one slot, as three pairs and a single, 5 fractional bits.
+// ((s0 >> 9) | (s1 >> 9) << 16) for two footprint sums in [1, 2^23): bytes 1..2 of each
+// (a shift by 8 for free in the byte shuffle), then one packed shift by 1.
+__device__ __forceinline__ uint32_t pack_shr9(int s0, int s1) {
+    const uint32_t p = __builtin_amdgcn_perm((uint32_t)s1, (uint32_t)s0, 0x06050201u);
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ushort2_t, p) >> (unsigned short)1);
+}
+
+// Interpolated window of one slot (I or J) with 5 fractional bits, CV_DESCALE(..., W_BITS-5),
+// as three pairs and a single.  The sums are at least 1: the only negative weight is -1.
 __device__ __forceinline__ void window_interp(const uint8_t* row0, int S, const Weights& wt,
                                               uint32_t& p01, uint32_t& p23, uint32_t& p45, int& p6) {
     const uint2 a = load_u8x8(row0), b = load_u8x8(row0 + S);
-    const int s0 = interp_px(px_pair<0>(a), px_pair<0>(b), wt);
-    const int s1 = interp_px(px_pair<1>(a), px_pair<1>(b), wt);
-    const int s2 = interp_px(px_pair<2>(a), px_pair<2>(b), wt);
-    const int s3 = interp_px(px_pair<3>(a), px_pair<3>(b), wt);
-    const int s4 = interp_px(px_pair<4>(a), px_pair<4>(b), wt);
-    const int s5 = interp_px(px_pair<5>(a), px_pair<5>(b), wt);
-    p6 = interp_px(px_pair<6>(a), px_pair<6>(b), wt);
-    p01 = pack16(s0, s1);
-    p23 = pack16(s2, s3);
-    p45 = pack16(s4, s5);
+    const uint32_t c0 = col_pair<0>(a, b), c1 = col_pair<1>(a, b), c2 = col_pair<2>(a, b),
+                   c3 = col_pair<3>(a, b), c4 = col_pair<4>(a, b), c5 = col_pair<5>(a, b),
+                   c6 = col_pair<6>(a, b), c7 = col_pair<7>(a, b);
+    constexpr int kRound = 1 << (W_BITS - 5 - 1);
+    const int s0 = footprint(c0, c1, wt, kRound), s1 = footprint(c1, c2, wt, kRound);
+    const int s2 = footprint(c2, c3, wt, kRound), s3 = footprint(c3, c4, wt, kRound);
+    const int s4 = footprint(c4, c5, wt, kRound), s5 = footprint(c5, c6, wt, kRound);
+    p6 = footprint(c6, c7, wt, kRound) >> (W_BITS - 5);
+    p01 = pack_shr9(s0, s1);
+    p23 = pack_shr9(s2, s3);
+    p45 = pack_shr9(s4, s5);
 }
 
 // LPP = lanes per point: 64 (one point per wave) or 16 (four points per wave, one per
@@ -522,16 +528,18 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
             uint32_t d0[8], d1[8];
             __builtin_memcpy(d0, D + o, 32);
             __builtin_memcpy(d1, D + o + S, 32);
+            // column pairs (row y, row y+1) of Ix and of Iy, then CV_DESCALE(..., W_BITS)
+            uint32_t xp[8], yp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xp[j] = __builtin_amdgcn_perm(d1[j], d0[j], 0x05040100u);
+                yp[j] = __builtin_amdgcn_perm(d1[j], d0[j], 0x07060302u);
+            }
             int ix[kPxPerSlot], iy[kPxPerSlot];
 #pragma unroll
             for (int j = 0; j < kPxPerSlot; ++j) {
-                // (Ix[j], Ix[j+1]) and (Iy[j], Iy[j+1]) as signed 16-bit pairs, rows y and y+1
-                const uint32_t x0 = __builtin_amdgcn_perm(d0[j + 1], d0[j], 0x05040100u);
-                const uint32_t y0 = __builtin_amdgcn_perm(d0[j + 1], d0[j], 0x07060302u);
-                const uint32_t x1 = __builtin_amdgcn_perm(d1[j + 1], d1[j], 0x05040100u);
-                const uint32_t y1 = __builtin_amdgcn_perm(d1[j + 1], d1[j], 0x07060302u);
-                ix[j] = interp_deriv(x0, x1, wt);
-                iy[j] = interp_deriv(y0, y1, wt);
+                ix[j] = footprint(xp[j], xp[j + 1], wt, 1 << (W_BITS - 1)) >> W_BITS;
+                iy[j] = footprint(yp[j], yp[j + 1], wt, 1 << (W_BITS - 1)) >> W_BITS;
             }
             w.x01 = pack16(ix[0], ix[1]) & w.m01;
             w.x23 = pack16(ix[2], ix[3]) & w.m23;
