@@ -204,3 +204,78 @@ def test_robust_matches_strided_rows(ctx, oracle):
         fwd = ctx.ratio_matches(capi.NORM_HAMMING, wide_a[:, 3:35], wide_b[:, 16:48], 0.7)
         idx, dist = oracle.knn2_hamming(a, b)
         assert fwd.tobytes() == oracle.ratio_filter(idx, dist, 900, 0.7).tobytes()
+
+
+@pytest.mark.parametrize("d,rows,counts", [
+    (32, 2600, [2600, 1025, 1024, 257, 2, 2049]),   # workgroup / batch boundaries of the pair kernel
+    (16, 1500, [1500, 1023, 300, 1, 1280, 64]),     # 16-byte descriptors: the 4-word instantiation
+    (13, 600, [600, 511, 257, 90, 600, 3]),         # padded to 16 bytes first
+    (64, 900, [900, 300, 700, 2, 899, 65]),         # 64-byte descriptors: the two-direction path
+])
+def test_match_pairs_ragged(ctx, oracle, d, rows, counts):
+    """Every pair of six frames with very different row counts, against the oracle."""
+    import torch
+
+    from sfm_amd import capi
+
+    rng = np.random.default_rng(1000 + d)
+    n_frames = len(counts)
+    base = rng.integers(0, 256, size=(rows, d), dtype=np.uint8)
+    frames = []
+    for f in range(n_frames):
+        fr = base.copy()
+        flip = rng.random(size=(rows, d * 8)) < 0.04
+        fr ^= np.packbits(flip, axis=1, bitorder="little")
+        fresh = rng.random(rows) < 0.3
+        fr[fresh] = rng.integers(0, 256, size=(int(fresh.sum()), d), dtype=np.uint8)
+        frames.append(fr[rng.permutation(rows)])
+    stack = np.stack(frames)
+    counts = np.array(counts, np.int32)
+    pairs = np.array([(i, j) for i in range(n_frames) for j in range(n_frames) if i != j], np.int32)
+    dev = torch.device("cuda:0")
+    d_desc = torch.from_numpy(stack).to(dev)
+    d_counts = torch.from_numpy(counts).to(dev)
+    d_pairs = torch.from_numpy(pairs).to(dev)
+    cap = rows
+    d_matches = torch.zeros((len(pairs), cap, 4), dtype=torch.int32, device=dev)
+    d_mc = torch.zeros(len(pairs), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.match_pairs_dev(capi.NORM_HAMMING, d_desc, n_frames, rows * d, rows, d_counts, d, d_pairs,
+                        len(pairs), 0.75, d_matches, cap, d_mc)
+    ctx.synchronize()
+    mc = d_mc.cpu().numpy()
+    m = d_matches.cpu().numpy().view(capi.DMATCH_DTYPE).reshape(len(pairs), cap)
+    total = 0
+    for p, (i, j) in enumerate(pairs):
+        want = oracle.robust_matches(oracle.NORM_HAMMING, stack[i][: counts[i]],
+                                     stack[j][: counts[j]], 0.75)
+        assert mc[p] == len(want), (i, j)
+        assert _tuples(m[p][: mc[p]]) == _tuples(want), (i, j)
+        total += len(want)
+    assert total > 200
+
+
+def test_two_direction_path_agrees(oracle):
+    """SFM_PAIR_KERNEL=0 routes pair matching through the single-direction kernel twice; it
+    must give what the one-pass pair kernel gives.  The switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from sfm_amd import capi, synth
+from oracle import pyoracle
+a, b = synth.descriptor_chain(2, 3000, 32, seed=21)
+b = b[:2500]
+got = capi.Context(0).robust_matches(capi.NORM_HAMMING, a, b, 0.7)
+want = pyoracle.robust_matches(pyoracle.NORM_HAMMING, a, b, 0.7)
+assert len(want) > 300 and got.tobytes() == want.tobytes()
+print("two-direction ok", len(got))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SFM_PAIR_KERNEL="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "two-direction ok" in out.stdout
