@@ -244,7 +244,14 @@ __global__ __launch_bounds__(kBlock) void hamming_pair_kernel(PairArgs a) {
 
 // Rows of prev one workgroup owns for a descriptor of `row_words` words, or 0 when this
 // kernel has no instantiation for that width.
-int hamming_pair_block_rows(int row_words) { return row_words == 8 || row_words == 4 ? kBlock * 4 : 0; }
+int hamming_pair_block_rows(int row_words) {
+    switch (row_words) {
+        case 4:
+        case 8: return kBlock * 4;  // Q = 4 rows of prev per lane
+        case 16: return kBlock * 2; // Q = 2: 64-byte rows take twice the registers
+        default: return 0;
+    }
+}
 
 PairPlan make_pair_plan(const sfm_ctx* ctx, int row_words, int rows_max, int n_pairs) {
     PairPlan p{};
@@ -293,6 +300,10 @@ int launch_hamming_pairs(sfm_ctx* ctx, const PairPlan& plan, const void* packed,
             break;
         case 8:
             hipLaunchKernelGGL((hamming_pair_kernel<8, 4, 4>), dim3((unsigned)grid), dim3(kBlock), 0,
+                               ctx->stream, a);
+            break;
+        case 16:
+            hipLaunchKernelGGL((hamming_pair_kernel<16, 2, 4>), dim3((unsigned)grid), dim3(kBlock), 0,
                                ctx->stream, a);
             break;
         default:
