@@ -49,12 +49,18 @@ bool is_packed(const void* p, size_t stride, int d, int row_words) {
 
 // Whether the one-pass pair kernel handles this row width.  SFM_PAIR_KERNEL=0 selects the
 // two-direction path for every width (a debugging and measurement aid).
-bool use_pair_kernel(int row_words) {
-    static const bool enabled = [] {
+// The pair kernel's unit of work is coarse (one wave: 256 rows of prev against a batch of
+// 256 rows of curr), so it needs enough of them to occupy the chip; a single small pair is
+// faster through the finely split single-direction kernel.
+bool use_pair_kernel(const sfm_ctx* ctx, int row_words, int rows_max, int n_pairs) {
+    static const int mode = [] {
         const char* e = getenv("SFM_PAIR_KERNEL");
-        return !(e && e[0] == '0');
+        return e ? atoi(e) : -1;  // 0: never, 1: whenever the width allows, unset: by size
     }();
-    return enabled && hamming_pair_block_rows(row_words) > 0;
+    if (mode == 0 || hamming_pair_block_rows(row_words) == 0) return false;
+    if (mode == 1) return true;
+    const long tiles = (rows_max + 255) / 256;
+    return (long)n_pairs * tiles * tiles >= 3L * ctx->num_cus;
 }
 
 // Hamming robust matching over frames already packed to plan.row_words words per
@@ -64,7 +70,7 @@ int hamming_pairs_packed(sfm_ctx* ctx, const KnnPlan& plan, const void* packed, 
                          int n_pairs, float ratio, sfm_dmatch* d_matches, int cap,
                          int32_t* d_match_counts, Carver& c) {
     const size_t nprob = 2 * (size_t)n_pairs;
-    if (use_pair_kernel(plan.row_words)) {
+    if (use_pair_kernel(ctx, plan.row_words, plan.rows_max, n_pairs)) {
         const PairPlan pp = make_pair_plan(ctx, plan.row_words, plan.rows_max, n_pairs);
         uint32_t* keys_row = c.take<uint32_t>((size_t)n_pairs * pp.splits * pp.rows_max * 2);
         uint32_t* keys_col = c.take<uint32_t>((size_t)n_pairs * pp.qblocks * pp.rows_max * 2);
@@ -94,7 +100,7 @@ int hamming_pairs_packed(sfm_ctx* ctx, const KnnPlan& plan, const void* packed, 
 size_t hamming_pairs_bytes(const sfm_ctx* ctx, const KnnPlan& plan, int n_pairs) {
     Carver c(nullptr);
     const size_t nprob = 2 * (size_t)n_pairs;
-    if (use_pair_kernel(plan.row_words)) {
+    if (use_pair_kernel(ctx, plan.row_words, plan.rows_max, n_pairs)) {
         const PairPlan pp = make_pair_plan(ctx, plan.row_words, plan.rows_max, n_pairs);
         c.take<uint32_t>((size_t)n_pairs * pp.splits * pp.rows_max * 2);
         c.take<uint32_t>((size_t)n_pairs * pp.qblocks * pp.rows_max * 2);

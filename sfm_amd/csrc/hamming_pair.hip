@@ -43,6 +43,7 @@ struct PairArgs {
     int splits;                // workgroups along curr
     int batches_per_split;
     int rows_max;
+    int grouped;               // 1: block -> pair mapping keeps 8 pairs per XCD label
     uint2* keys_row;           // [pair][split][rows_max]
     uint2* keys_col;           // [pair][qblock][rows_max]
 };
@@ -90,13 +91,19 @@ __global__ __launch_bounds__(kBlock) void hamming_pair_kernel(PairArgs a) {
     __shared__ uint4 col1[kWaves][64], col2[kWaves][64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Groups of 8 pairs share an XCD label (blockIdx % 8) so that a pair's two frames stay
-    // in one XCD's L2.
+    // With many pairs, groups of 8 pairs share an XCD label (blockIdx % 8) so that a pair's
+    // two frames stay in one XCD's L2; a few pairs are spread over all XCDs instead.
     const int per_pair = a.qblocks * a.splits;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int pair = (slot / per_pair) * 8 + xcd;
+    int pair, inner;
+    if (a.grouped) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pair = (slot / per_pair) * 8 + xcd;
+        inner = slot % per_pair;
+    } else {
+        pair = blockIdx.x / per_pair;
+        inner = blockIdx.x % per_pair;
+    }
     if (pair >= a.n_pairs) return;
-    const int inner = slot % per_pair;
     const int qb = inner / a.splits, split = inner % a.splits;
     const int fa = a.pairs[2 * pair], fb = a.pairs[2 * pair + 1];
     const int n_prev = a.counts ? a.counts[fa] : a.rows_uniform;
@@ -289,7 +296,8 @@ int launch_hamming_pairs(sfm_ctx* ctx, const PairPlan& plan, const void* packed,
     a.rows_max = plan.rows_max;
     a.keys_row = reinterpret_cast<uint2*>(d_keys_row);
     a.keys_col = reinterpret_cast<uint2*>(d_keys_col);
-    const long pairs_padded = (long)((n_pairs + 7) / 8) * 8;
+    a.grouped = n_pairs >= 64 ? 1 : 0;
+    const long pairs_padded = a.grouped ? (long)((n_pairs + 7) / 8) * 8 : n_pairs;
     const long grid = pairs_padded * plan.qblocks * plan.splits;
     if (grid > 0x7fffffffL) return set_error(ctx, SFM_E_INVALID, "pair launch too large");
     KernelTimer timer(ctx, KID_HAMMING_PAIR);

@@ -209,11 +209,12 @@ def test_robust_matches_strided_rows(ctx, oracle):
 @pytest.mark.parametrize("d,rows,counts", [
     (32, 2600, [2600, 1025, 1024, 257, 2, 2049]),   # workgroup / batch boundaries of the pair kernel
     (16, 1500, [1500, 1023, 300, 1, 1280, 64]),     # 16-byte descriptors: the 4-word instantiation
-    (13, 600, [600, 511, 257, 90, 600, 3]),         # padded to 16 bytes first
-    (64, 900, [900, 300, 700, 2, 899, 65]),         # 64-byte descriptors: two rows of prev per lane
+    (13, 1300, [1300, 511, 257, 90, 1299, 3]),      # padded to 16 bytes first
+    (64, 1300, [1300, 300, 700, 2, 1025, 65]),      # 64-byte descriptors: two rows of prev per lane
 ])
 def test_match_pairs_ragged(ctx, oracle, d, rows, counts):
-    """Every pair of six frames with very different row counts, against the oracle."""
+    """Every pair of six frames with very different row counts, against the oracle (30 pairs
+    of this size go through the one-pass pair kernel)."""
     import torch
 
     from sfm_amd import capi
