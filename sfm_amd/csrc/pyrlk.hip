@@ -123,24 +123,30 @@ __global__ void lk_pyr_down_kernel(LkGeom g, int level, uint8_t* __restrict__ py
         const int x = x4 - g.bw;
         uint32_t v = 0;
         if (x >= 0 && x + 4 <= w) {
-            // source columns 2x-2 .. 2x+8 of rows 2ry-2 .. 2ry+2
-            int col[4] = {0, 0, 0, 0};
+            // source columns 2x-2 .. 2x+8 of rows 2ry-2 .. 2ry+2.  Output i takes the five
+            // bytes 2i .. 2i+4 of a row with weights 1 4 6 4 1: a byte dot product over
+            // four of them plus a second one that picks the fifth.
+            constexpr uint32_t kW = 0x04060401u;              // weights of bytes 0..3
+            constexpr uint32_t kE0 = 0x00000001u, kE2 = 0x00010000u;  // byte 0 / byte 2 alone
+            uint32_t col[4] = {128u, 128u, 128u, 128u};       // rounding of the final >> 8
             const uint8_t* s = src + (ptrdiff_t)(2 * ry - 2) * SS + (2 * x - 2);
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 uint32_t q[4];
                 __builtin_memcpy(q, s + (ptrdiff_t)k * SS, 16);
-                int b[12];
-#pragma unroll
-                for (int i = 0; i < 12; ++i) b[i] = (q[i >> 2] >> (8 * (i & 3))) & 0xFF;
-                const int wk = k == 2 ? 6 : (k == 1 || k == 3) ? 4 : 1;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    col[i] += wk * (b[2 * i + 2] * 6 + (b[2 * i + 1] + b[2 * i + 3]) * 4 + b[2 * i] +
-                                    b[2 * i + 4]);
+                const uint32_t m01 = __builtin_amdgcn_alignbyte(q[1], q[0], 2);  // bytes 2..5
+                const uint32_t m12 = __builtin_amdgcn_alignbyte(q[2], q[1], 2);  // bytes 6..9
+                const uint32_t h0 = __builtin_amdgcn_udot4(q[0], kW, __builtin_amdgcn_udot4(q[1], kE0, 0u, false), false);
+                const uint32_t h1 = __builtin_amdgcn_udot4(m01, kW, __builtin_amdgcn_udot4(q[1], kE2, 0u, false), false);
+                const uint32_t h2 = __builtin_amdgcn_udot4(q[1], kW, __builtin_amdgcn_udot4(q[2], kE0, 0u, false), false);
+                const uint32_t h3 = __builtin_amdgcn_udot4(m12, kW, __builtin_amdgcn_udot4(q[2], kE2, 0u, false), false);
+                const uint32_t wk = k == 2 ? 6u : (k == 1 || k == 3) ? 4u : 1u;
+                col[0] += wk * h0;
+                col[1] += wk * h1;
+                col[2] += wk * h2;
+                col[3] += wk * h3;
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v |= (uint32_t)((col[i] + 128) >> 8) << (8 * i);
+            v = (col[0] >> 8) | ((col[1] >> 8) << 8) | ((col[2] >> 8) << 16) | ((col[3] >> 8) << 24);
         } else {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -446,7 +452,12 @@ __device__ __forceinline__ void window_interp(const uint8_t* row0, int S, const 
 template <int LPP, int SPL>
 __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
     const int lane = threadIdx.x & (LPP - 1);
-    const int pt_raw = (blockIdx.x * 256 + threadIdx.x) / LPP;
+    // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); give each XCD one
+    // contiguous eighth of the points, so that an image pair's pyramids are fetched into
+    // one L2 instead of all eight.
+    const int per_xcd = gridDim.x >> 3;
+    const int pblock = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int pt_raw = (pblock * 256 + threadIdx.x) / LPP;
     if (LPP == 64 && pt_raw >= a.n_total) return;  // wave-uniform
     if (LPP == 16 && (pt_raw & ~3) >= a.n_total) return;  // whole wave past the end
     const bool pt_live = pt_raw < a.n_total;
@@ -842,7 +853,7 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     KernelTimer timer(ctx, KID_LK_TRACK);
     if (a.slots <= 64) {
         // four points per wave, 16 lanes each
-        const dim3 grid((a.n_total + 15) / 16);
+        const dim3 grid((((a.n_total + 15) / 16 + 7) / 8) * 8);  // a multiple of 8, see the kernel
         switch ((a.slots + 15) / 16) {
             case 1: hipLaunchKernelGGL((lk_track_kernel<16, 1>), grid, blk, 0, ctx->stream, a); break;
             case 2: hipLaunchKernelGGL((lk_track_kernel<16, 2>), grid, blk, 0, ctx->stream, a); break;
@@ -850,7 +861,7 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             default: hipLaunchKernelGGL((lk_track_kernel<16, 4>), grid, blk, 0, ctx->stream, a); break;
         }
     } else {
-        const dim3 grid((a.n_total + 3) / 4);
+        const dim3 grid((((a.n_total + 3) / 4 + 7) / 8) * 8);
         switch ((a.slots + 63) / 64) {
             case 2: hipLaunchKernelGGL((lk_track_kernel<64, 2>), grid, blk, 0, ctx->stream, a); break;
             case 3: hipLaunchKernelGGL((lk_track_kernel<64, 3>), grid, blk, 0, ctx->stream, a); break;
