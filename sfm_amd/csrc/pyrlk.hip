@@ -38,8 +38,22 @@ struct LkGeom {
     int stride[kMaxLevels];     // elements per padded row (bytes for images, words for deriv)
     size_t img_off[kMaxLevels]; // offset of pixel (0,0) of level l inside one image block
     size_t block;               // elements per image block (all levels)
-    int bw, bh;                 // border = window size
+    int bw, bh;                 // left / top border: window width rounded up to 16, window height
 };
+
+// t / d and t % d for 0 <= t < 2^23, 0 < d < 2^23 by a float reciprocal and one fix-up
+// (an integer division costs about forty instructions).
+__device__ __forceinline__ void divmod_small(int t, int d, int& q, int& r) {
+    q = (int)((float)t * __frcp_rn((float)d));
+    r = t - q * d;
+    if (r < 0) {
+        --q;
+        r += d;
+    } else if (r >= d) {
+        ++q;
+        r -= d;
+    }
+}
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     if ((unsigned)p < (unsigned)len) return p;
@@ -68,14 +82,24 @@ __global__ void lk_pad_level0_kernel(const uint8_t* __restrict__ prev,
     const int S = g.stride[0], w = g.w[0], h = g.h[0];
     const int per_row = S / 16, total = per_row * (h + 2 * g.bh);
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const int y = t / per_row - g.bh, x16 = (t % per_row) * 16;
+        int yy, xg;
+        divmod_small(t, per_row, yy, xg);
+        const int y = yy - g.bh, x16 = xg * 16;
         const int sy = reflect101(y, h);
         const uint8_t* srow = src + (size_t)sy * row_stride;
         uint8_t* drow = dst + (ptrdiff_t)y * S - g.bw;
         const int x = x16 - g.bw;
         uint4 v;
+        // reflect-101 of a whole group that lies left (m = -x - 15) or right (m = 2(w-1) - x - 15)
+        // of the image: the 16 source bytes m .. m+15 in reverse order
+        const int m = x + 16 <= 0 ? -x - 15 : 2 * (w - 1) - x - 15;
         if (x >= 0 && x + 16 <= w) {
             __builtin_memcpy(&v, srow + x, 16);
+        } else if ((x + 16 <= 0 || (x >= w && x + 16 <= w + g.bw)) && m >= 0 && m + 16 <= w) {
+            uint4 r;
+            __builtin_memcpy(&r, srow + m, 16);
+            v = make_uint4(__builtin_bswap32(r.w), __builtin_bswap32(r.z), __builtin_bswap32(r.y),
+                           __builtin_bswap32(r.x));
         } else {
             uint32_t q[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -104,9 +128,38 @@ __device__ __forceinline__ uint32_t pyr_down_px(const uint8_t* src, int SS, int 
     return (uint32_t)((acc + 128) >> 8);
 }
 
+// Four horizontally adjacent pyrDown outputs (x .. x+3, row ry, all inside the level) as
+// packed bytes.  Output i takes the five source bytes 2i .. 2i+4 of a row with weights
+// 1 4 6 4 1: a byte dot product over four of them plus a second one that picks the fifth.
+__device__ __forceinline__ uint32_t pyr_down_quad(const uint8_t* src, int SS, int x, int ry) {
+    constexpr uint32_t kW = 0x04060401u;                      // weights of bytes 0..3
+    constexpr uint32_t kE0 = 0x00000001u, kE2 = 0x00010000u;  // byte 0 / byte 2 alone
+    uint32_t col[4] = {128u, 128u, 128u, 128u};               // rounding of the final >> 8
+    // source columns 2x-2 .. 2x+8 of rows 2ry-2 .. 2ry+2
+    const uint8_t* s = src + (ptrdiff_t)(2 * ry - 2) * SS + (2 * x - 2);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        uint32_t q[4];
+        __builtin_memcpy(q, s + (ptrdiff_t)k * SS, 16);
+        const uint32_t m01 = __builtin_amdgcn_alignbyte(q[1], q[0], 2);  // bytes 2..5
+        const uint32_t m12 = __builtin_amdgcn_alignbyte(q[2], q[1], 2);  // bytes 6..9
+        const uint32_t h0 = __builtin_amdgcn_udot4(q[0], kW, __builtin_amdgcn_udot4(q[1], kE0, 0u, false), false);
+        const uint32_t h1 = __builtin_amdgcn_udot4(m01, kW, __builtin_amdgcn_udot4(q[1], kE2, 0u, false), false);
+        const uint32_t h2 = __builtin_amdgcn_udot4(q[1], kW, __builtin_amdgcn_udot4(q[2], kE0, 0u, false), false);
+        const uint32_t h3 = __builtin_amdgcn_udot4(m12, kW, __builtin_amdgcn_udot4(q[2], kE2, 0u, false), false);
+        const uint32_t wk = k == 2 ? 6u : (k == 1 || k == 3) ? 4u : 1u;
+        col[0] += wk * h0;
+        col[1] += wk * h1;
+        col[2] += wk * h2;
+        col[3] += wk * h3;
+    }
+    return (col[0] >> 8) | ((col[1] >> 8) << 8) | ((col[2] >> 8) << 16) | ((col[3] >> 8) << 24);
+}
+
 // Level l (>= 1) of both images from level l-1, including its reflect-101 border.
-// One thread writes 4 output pixels; in the interior they share five 16-byte
-// source loads (11 source columns x 5 rows).
+// One thread writes 4 output pixels; a group inside the image shares five 16-byte source
+// loads (11 source columns x 5 rows), a group in the left or right border is the reversed
+// group of the mirrored image columns.
 __global__ void lk_pyr_down_kernel(LkGeom g, int level, uint8_t* __restrict__ pyr_prev,
                                    uint8_t* __restrict__ pyr_curr) {
     const int pair = blockIdx.z >> 1, which = blockIdx.z & 1;
@@ -117,36 +170,18 @@ __global__ void lk_pyr_down_kernel(LkGeom g, int level, uint8_t* __restrict__ py
     const int S = g.stride[level], w = g.w[level], h = g.h[level];
     const int per_row = S / 4, total = per_row * (h + 2 * g.bh);
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const int y = t / per_row - g.bh, x4 = (t % per_row) * 4;
+        int yy, xg;
+        divmod_small(t, per_row, yy, xg);
+        const int y = yy - g.bh, x4 = xg * 4;
         const int ry = reflect101(y, h);
         uint8_t* drow = dst + (ptrdiff_t)y * S - g.bw;
         const int x = x4 - g.bw;
+        const int m = x + 4 <= 0 ? -x - 3 : 2 * (w - 1) - x - 3;  // first column of the mirrored group
         uint32_t v = 0;
         if (x >= 0 && x + 4 <= w) {
-            // source columns 2x-2 .. 2x+8 of rows 2ry-2 .. 2ry+2.  Output i takes the five
-            // bytes 2i .. 2i+4 of a row with weights 1 4 6 4 1: a byte dot product over
-            // four of them plus a second one that picks the fifth.
-            constexpr uint32_t kW = 0x04060401u;              // weights of bytes 0..3
-            constexpr uint32_t kE0 = 0x00000001u, kE2 = 0x00010000u;  // byte 0 / byte 2 alone
-            uint32_t col[4] = {128u, 128u, 128u, 128u};       // rounding of the final >> 8
-            const uint8_t* s = src + (ptrdiff_t)(2 * ry - 2) * SS + (2 * x - 2);
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                uint32_t q[4];
-                __builtin_memcpy(q, s + (ptrdiff_t)k * SS, 16);
-                const uint32_t m01 = __builtin_amdgcn_alignbyte(q[1], q[0], 2);  // bytes 2..5
-                const uint32_t m12 = __builtin_amdgcn_alignbyte(q[2], q[1], 2);  // bytes 6..9
-                const uint32_t h0 = __builtin_amdgcn_udot4(q[0], kW, __builtin_amdgcn_udot4(q[1], kE0, 0u, false), false);
-                const uint32_t h1 = __builtin_amdgcn_udot4(m01, kW, __builtin_amdgcn_udot4(q[1], kE2, 0u, false), false);
-                const uint32_t h2 = __builtin_amdgcn_udot4(q[1], kW, __builtin_amdgcn_udot4(q[2], kE0, 0u, false), false);
-                const uint32_t h3 = __builtin_amdgcn_udot4(m12, kW, __builtin_amdgcn_udot4(q[2], kE2, 0u, false), false);
-                const uint32_t wk = k == 2 ? 6u : (k == 1 || k == 3) ? 4u : 1u;
-                col[0] += wk * h0;
-                col[1] += wk * h1;
-                col[2] += wk * h2;
-                col[3] += wk * h3;
-            }
-            v = (col[0] >> 8) | ((col[1] >> 8) << 8) | ((col[2] >> 8) << 16) | ((col[3] >> 8) << 24);
+            v = pyr_down_quad(src, SS, x, ry);
+        } else if ((x + 4 <= 0 || (x >= w && x + 4 <= w + g.bw)) && m >= 0 && m + 4 <= w) {
+            v = __builtin_bswap32(pyr_down_quad(src, SS, m, ry));
         } else {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -170,7 +205,9 @@ __global__ void lk_scharr_kernel(LkGeom g, const uint8_t* __restrict__ pyr_prev,
     const int S = g.stride[level], w = g.w[level], h = g.h[level];
     const int per_row = S / 4, total = per_row * (h + 2 * g.bh);
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const int y = t / per_row - g.bh, xi = (t % per_row) * 4;
+        int yy, xg;
+        divmod_small(t, per_row, yy, xg);
+        const int y = yy - g.bh, xi = xg * 4;
         const int x0 = xi - g.bw;  // image column of the first of the four pixels
         uint32_t out[4] = {0, 0, 0, 0};
         if (y >= 0 && y < h && x0 + 3 >= 0 && x0 < w) {
@@ -699,7 +736,10 @@ int lk_num_levels(int w, int h, int win_w, int win_h, int max_level) {
 int make_geom(int width, int height, int win_w, int win_h, int max_level, LkGeom* g) {
     if (max_level > kMaxLevels - 1) max_level = kMaxLevels - 1;
     g->levels = lk_num_levels(width, height, win_w, win_h, max_level);
-    g->bw = win_w;
+    // Left border rounded up to 16 columns: every 16-byte (level 0) or 4-pixel (other levels)
+    // group of a padded row then lies entirely in the border or entirely in the image, and a
+    // border group is the byte-reversed copy of an image group.
+    g->bw = (int)align_up((size_t)win_w, 16);
     g->bh = win_h;
     size_t off = 0;
     int w = width, h = height;
@@ -707,10 +747,10 @@ int make_geom(int width, int height, int win_w, int win_h, int max_level, LkGeom
         g->w[l] = w;
         g->h[l] = h;
         // 8 extra columns: a slot's 8-element loads may run past the window
-        g->stride[l] = (int)align_up((size_t)w + 2 * win_w + 8, 16);
+        g->stride[l] = (int)align_up((size_t)w + g->bw + win_w + 8, 16);
         // every padded row starts 16-byte aligned (off is a multiple of 64)
-        g->img_off[l] = off + (size_t)win_h * g->stride[l] + (size_t)win_w;
-        off = align_up(g->img_off[l] - win_w + (size_t)(h + win_h) * g->stride[l] + 64, 64);
+        g->img_off[l] = off + (size_t)win_h * g->stride[l] + (size_t)g->bw;
+        off = align_up(g->img_off[l] - g->bw + (size_t)(h + win_h) * g->stride[l] + 64, 64);
         w = (w + 1) / 2;
         h = (h + 1) / 2;
     }
