@@ -256,7 +256,7 @@ struct LkArgs {
     const uint32_t* deriv;
     const float2* prev_pts;
     int n;        // points per pair
-    int n_total;  // n * n_pairs
+    int n_pairs;
     int win_w, win_h, segs, slots;
     int max_count;
     double epsilon;  // already squared
@@ -374,9 +374,10 @@ __device__ __forceinline__ void row_sum_wide_n(const int (&p)[N], int (&lo)[N], 
     }
 }
 
-// (float)(hi * 65536 + lo) with one rounding: both terms and their sum are exact in double.
+// (float)(hi * 65536 + lo) with one rounding, for |hi| < 2^24 and |lo| < 2^24: both
+// conversions and the scaling by 2^16 are exact, so the only rounding is the final add.
 __device__ __forceinline__ float halves_to_float(int hi, int lo) {
-    return (float)((double)hi * 65536.0 + (double)lo);
+    return (float)hi * 65536.f + (float)lo;
 }
 
 __device__ __forceinline__ uint2 load_u8x8(const uint8_t* p) {
@@ -468,9 +469,11 @@ __device__ __forceinline__ uint32_t pack_shr9(int s0, int s1) {
 
 // Interpolated window of one slot (I or J) with 5 fractional bits, CV_DESCALE(..., W_BITS-5),
 // as three pairs and a single.  The sums are at least 1: the only negative weight is -1.
-__device__ __forceinline__ void window_interp(const uint8_t* row0, int S, const Weights& wt,
+// The two rows sit at base + o and base + o + S; base is wave-uniform and both offsets are
+// 32-bit, so the loads need no 64-bit address arithmetic per lane.
+__device__ __forceinline__ void window_interp(const uint8_t* base, unsigned o, int S, const Weights& wt,
                                               uint32_t& p01, uint32_t& p23, uint32_t& p45, int& p6) {
-    const uint2 a = load_u8x8(row0), b = load_u8x8(row0 + S);
+    const uint2 a = load_u8x8(base + o), b = load_u8x8(base + (o + (unsigned)S));
     const uint32_t c0 = col_pair<0>(a, b), c1 = col_pair<1>(a, b), c2 = col_pair<2>(a, b),
                    c3 = col_pair<3>(a, b), c4 = col_pair<4>(a, b), c5 = col_pair<5>(a, b),
                    c6 = col_pair<6>(a, b), c7 = col_pair<7>(a, b);
@@ -494,12 +497,16 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
     // one L2 instead of all eight.
     const int per_xcd = gridDim.x >> 3;
     const int pblock = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int pt_raw = (pblock * 256 + threadIdx.x) / LPP;
-    if (LPP == 64 && pt_raw >= a.n_total) return;  // wave-uniform
-    if (LPP == 16 && (pt_raw & ~3) >= a.n_total) return;  // whole wave past the end
-    const bool pt_live = pt_raw < a.n_total;
-    const int pt = pt_live ? pt_raw : a.n_total - 1;  // surplus rows repeat the last point
-    const int pair = pt / a.n;
+    // A wave never mixes points of two image pairs: the pyramid base addresses are then
+    // wave-uniform (scalar registers, 32-bit lane offsets).
+    constexpr int kPerWave = 64 / LPP;
+    const int waves_per_pair = (a.n + kPerWave - 1) / kPerWave;
+    const int wave_id = __builtin_amdgcn_readfirstlane(pblock * 4 + (int)(threadIdx.x >> 6));
+    const int pair = wave_id / waves_per_pair;
+    if (pair >= a.n_pairs) return;  // wave-uniform
+    const int local_raw = (wave_id - pair * waves_per_pair) * kPerWave + (int)(threadIdx.x & 63) / LPP;
+    const bool pt_live = local_raw < a.n;
+    const int pt = pair * a.n + (pt_live ? local_raw : a.n - 1);  // surplus rows repeat the last point
     const LkGeom& g = a.g;
     const uint8_t* pyrI = a.pyr_prev + (size_t)pair * g.block;
     const uint8_t* pyrJ = a.pyr_curr + (size_t)pair * g.block;
@@ -560,22 +567,27 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
             continue;
         }
         Weights wt = bilinear_weights(prev_x - ipx, prev_y - ipy);
+        // offset of each slot inside a window at this level's row pitch
+        unsigned soff[SPL];
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) soff[s] = (unsigned)(srow[s] * S + sx0[s]);
 
         int pA[3] = {0, 0, 0};
+        const unsigned obase = (unsigned)((ipy + g.bh) * S + ipx + g.bw);
 #pragma unroll
         for (int s = 0; s < SPL; ++s) {
             SlotWin& w = win[s];
-            const unsigned o = (unsigned)((ipy + g.bh + srow[s]) * S + ipx + g.bw + sx0[s]);
+            const unsigned o = obase + soff[s];
             uint32_t i01, i23, i45;
             int i6;
-            window_interp(I + o, S, wt, i01, i23, i45, i6);
+            window_interp(I, o, S, wt, i01, i23, i45, i6);
             w.i01 = i01 & w.m01;
             w.i23 = i23 & w.m23;
             w.i45 = i45 & w.m45;
             w.i6 = i6 & w.m6;
             uint32_t d0[8], d1[8];
             __builtin_memcpy(d0, D + o, 32);
-            __builtin_memcpy(d1, D + o + S, 32);
+            __builtin_memcpy(d1, D + (o + (unsigned)S), 32);
             // column pairs (row y, row y+1) of Ix and of Iy, then CV_DESCALE(..., W_BITS)
             uint32_t xp[8], yp[8];
 #pragma unroll
@@ -637,13 +649,14 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
             }
             wt = bilinear_weights(next_x - inx, next_y - iny);
             int pb[2] = {0, 0};
+            const unsigned jbase = (unsigned)((iny + g.bh) * S + inx + g.bw);
 #pragma unroll
             for (int s = 0; s < SPL; ++s) {
                 const SlotWin& w = win[s];
-                const unsigned o = (unsigned)((iny + g.bh + srow[s]) * S + inx + g.bw + sx0[s]);
+                const unsigned o = jbase + soff[s];
                 uint32_t j01, j23, j45;
                 int j6;
-                window_interp(J + o, S, wt, j01, j23, j45, j6);
+                window_interp(J, o, S, wt, j01, j23, j45, j6);
                 // mismatch J - I; the derivative pairs are 0 outside the window
                 const uint32_t d01 = pk_sub_i16(j01, w.i01), d23 = pk_sub_i16(j23, w.i23),
                                d45 = pk_sub_i16(j45, w.i45);
@@ -687,13 +700,14 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
             } else {
                 wt = bilinear_weights(ex - inx, ey - iny);
                 int perr[1] = {0};
+                const unsigned ebase = (unsigned)((iny + g.bh) * S + inx + g.bw);
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) {
                     const SlotWin& w = win[s];
-                    const unsigned o = (unsigned)((iny + g.bh + srow[s]) * S + inx + g.bw + sx0[s]);
+                    const unsigned o = ebase + soff[s];
                     uint32_t j01, j23, j45;
                     int j6;
-                    window_interp(J + o, S, wt, j01, j23, j45, j6);
+                    window_interp(J, o, S, wt, j01, j23, j45, j6);
                     const uint32_t dd[3] = {pk_sub_i16(j01, w.i01) & w.m01, pk_sub_i16(j23, w.i23) & w.m23,
                                             pk_sub_i16(j45, w.i45) & w.m45};
 #pragma unroll
@@ -877,7 +891,7 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     a.deriv = bufs.deriv;
     a.prev_pts = reinterpret_cast<const float2*>(d_prev_pts);
     a.n = n;
-    a.n_total = n * n_pairs;
+    a.n_pairs = n_pairs;
     a.win_w = win_w;
     a.win_h = win_h;
     a.segs = (win_w + kPxPerSlot - 1) / kPxPerSlot;
@@ -893,7 +907,9 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     KernelTimer timer(ctx, KID_LK_TRACK);
     if (a.slots <= 64) {
         // four points per wave, 16 lanes each
-        const dim3 grid((((a.n_total + 15) / 16 + 7) / 8) * 8);  // a multiple of 8, see the kernel
+        // four waves per workgroup, four points per wave; a multiple of 8 workgroups (see the kernel)
+        const long waves = (long)n_pairs * ((n + 3) / 4);
+        const dim3 grid((unsigned)((((waves + 3) / 4 + 7) / 8) * 8));
         switch ((a.slots + 15) / 16) {
             case 1: hipLaunchKernelGGL((lk_track_kernel<16, 1>), grid, blk, 0, ctx->stream, a); break;
             case 2: hipLaunchKernelGGL((lk_track_kernel<16, 2>), grid, blk, 0, ctx->stream, a); break;
@@ -901,7 +917,8 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             default: hipLaunchKernelGGL((lk_track_kernel<16, 4>), grid, blk, 0, ctx->stream, a); break;
         }
     } else {
-        const dim3 grid((((a.n_total + 3) / 4 + 7) / 8) * 8);
+        const long waves = (long)n_pairs * n;  // one point per wave
+        const dim3 grid((unsigned)((((waves + 3) / 4 + 7) / 8) * 8));
         switch ((a.slots + 63) / 64) {
             case 2: hipLaunchKernelGGL((lk_track_kernel<64, 2>), grid, blk, 0, ctx->stream, a); break;
             case 3: hipLaunchKernelGGL((lk_track_kernel<64, 3>), grid, blk, 0, ctx->stream, a); break;
