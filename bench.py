@@ -218,31 +218,30 @@ def run_framepair(args, rank, world, local):
         ctx_lk.reserve(capi.Context.pyrlk_workspace(P, LK_W, LK_H, LK_WIN, LK_MAXLEVEL))
     torch.cuda.synchronize()
 
-    def match_fn(_sub):
-        ctx.match_pairs_dev(capi.NORM_HAMMING, d_desc, P + 1, KPS * DESC_BYTES, KPS, None,
-                            DESC_BYTES, d_pairs, P, 0.5, d_matches, cap, d_mcount)
-        if world == 1:
-            return d_mcount, None
-        return d_mcount, allpairs.compact_matches(d_matches, d_mcount)
-
-    global_pairs = np.zeros((P * world, 2), np.int32)  # pair k lives on rank k % world
+    # N > 1: every rank matches its own pairs, then all ranks exchange their match lists
+    # (fixed-capacity buffers + counts, no host round trip); the collective is asynchronous
+    # and overlaps the tracking kernels of the same step.
+    gather = allpairs.PaddedGather(P, cap, world, dev) if world > 1 else None
     gathered = {}
 
     def step():
-        if world == 1:
-            match_fn(None)
-        else:
-            c, off, m = allpairs.match_all_pairs(global_pairs, match_fn, rank, world)
-            gathered["n"] = int(off[-1])
+        ctx.match_pairs_dev(capi.NORM_HAMMING, d_desc, P + 1, KPS * DESC_BYTES, KPS, None,
+                            DESC_BYTES, d_pairs, P, 0.5, d_matches, cap, d_mcount)
+        if gather is not None:
+            gather.start(d_matches, d_mcount)
         ctx_lk.pyrlk_batch_dev(d_prev, d_curr, P, LK_W * LK_H, LK_W, LK_H, LK_W, d_pts, LK_POINTS,
                                LK_WIN, LK_MAXLEVEL, 3, LK_COUNT, LK_EPS, 1e-4, 10.0, d_out,
                                d_status, d_err)
+        if gather is not None:
+            gather.wait()
 
     dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, ctx,
                            () if ctx_lk is ctx else (ctx_lk,))
     feats_step = world * P * (2 * KPS + LK_POINTS)
     value = feats_step * args.steps / dt
     matched = int(d_mcount.sum().item())
+    if gather is not None:
+        gathered["n"] = int(gather.counts.sum().item())
     tracked = int(d_status.sum().item())
 
     # roofline of the dominant kernel (by summed device time over the timed region)

@@ -61,6 +61,37 @@ def compact_matches(d_matches, d_counts):
     return d_matches[keep][:, [0, 1, 3]].contiguous()
 
 
+class PaddedGather:
+    """All-gather of fixed-capacity match buffers with no host synchronisation.
+
+    Every rank contributes its [P, cap, 4] int32 match buffer (cv::DMatch layout) and its [P]
+    counts as they are; `start` only enqueues the two collectives (asynchronously, so kernels
+    launched afterwards overlap them) and `wait` makes the current stream wait for them.  The
+    gathered tensors are [world, P, cap, 4] and [world, P]: rank r's pair p is at [r, p].
+    Meant for per-frame-pair use, where P is small and a compaction would cost a host round
+    trip per step; windowed matching over many pairs uses `match_all_pairs`.
+    """
+
+    def __init__(self, P, cap, world, device, group=None):
+        self.world, self.group = world, group
+        self.matches = torch.empty((world, P, cap, 4), dtype=torch.int32, device=device)
+        self.counts = torch.empty((world, P), dtype=torch.int32, device=device)
+        self._work = ()
+
+    def start(self, d_matches, d_counts):
+        self._work = (
+            dist.all_gather_into_tensor(self.counts.view(-1), d_counts.view(-1), group=self.group,
+                                        async_op=True),
+            dist.all_gather_into_tensor(self.matches.view(-1), d_matches.view(-1), group=self.group,
+                                        async_op=True),
+        )
+
+    def wait(self):
+        for w in self._work:
+            w.wait()
+        self._work = ()
+
+
 def match_all_pairs(pairs, match_fn, rank=0, world=1, group=None):
     """Runs match_fn on this rank's share of `pairs` and gathers every rank's result.
 

@@ -163,3 +163,40 @@ def test_all_pairs_gather_gloo_world2(tmp_path, oracle):
         np.testing.assert_array_equal(got["c"], np.array(want_c))
         np.testing.assert_array_equal(got["off"], np.concatenate([[0], np.cumsum(want_c)]))
         np.testing.assert_array_equal(got["m"], want_m)
+
+
+_PADDED_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from sfm_amd import allpairs
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+P, cap = 3, 5
+g = allpairs.PaddedGather(P, cap, world, torch.device("cpu"))
+for step in range(2):
+    m = (torch.arange(P * cap * 4, dtype=torch.int32).reshape(P, cap, 4) + 1000 * rank + 7 * step)
+    c = torch.tensor([rank + 1, 0, 5 - step], dtype=torch.int32)
+    g.start(m, c)
+    g.wait()
+    for r in range(world):
+        want = torch.arange(P * cap * 4, dtype=torch.int32).reshape(P, cap, 4) + 1000 * r + 7 * step
+        assert torch.equal(g.matches[r], want)
+        assert g.counts[r].tolist() == [r + 1, 0, 5 - step]
+dist.barrier()
+dist.destroy_process_group()
+print("padded gather ok")
+"""
+
+
+def test_padded_gather_gloo_world2(tmp_path):
+    """The sync-free all-gather of fixed-capacity match buffers the per-frame-pair bench uses."""
+    script = tmp_path / "padded_worker.py"
+    script.write_text(_PADDED_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29618", WORLD_SIZE="2",
+               OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
