@@ -177,3 +177,24 @@ def test_pyrlk_host_region_of_interest(ctx, oracle):
         np.testing.assert_array_equal(st, ost)
         np.testing.assert_array_equal(nxt, onxt)
         np.testing.assert_array_equal(err, oerr)
+
+
+@pytest.mark.parametrize("h,w,win,max_level", [
+    (33, 40, (9, 9), 2),      # narrower than two borders: per-byte reflect path everywhere
+    (45, 70, (21, 21), 3),    # window almost as large as the top level
+    (97, 131, (13, 7), 3),    # odd sizes, non-square window
+    (64, 1283, (21, 21), 1),  # wide row, width not a multiple of 4 or 16
+])
+def test_pyrlk_small_and_odd_images(ctx, oracle, h, w, win, max_level):
+    """Border construction (mirrored groups, straddling groups, tiny levels) against the oracle;
+    points right at the image edge so windows reach into the reflect-101 border."""
+    prev, curr, _ = _pair(h, w, 900 + h + w, 4)
+    rng = np.random.default_rng(h * w)
+    pts = np.stack([rng.uniform(0, w - 1, 200), rng.uniform(0, h - 1, 200)], 1).astype(np.float32)
+    pts[:8] = [[0, 0], [w - 1, 0], [0, h - 1], [w - 1, h - 1], [0.5, h / 2], [w - 1.5, h / 2],
+               [w / 2, 0.25], [w / 2, h - 1.25]]
+    nxt, st, err = ctx.pyrlk(prev, curr, pts, win=win, max_level=max_level)
+    onxt, ost, oerr = oracle.pyrlk(prev, curr, pts, win=win, max_level=max_level, acc_exact=True)
+    np.testing.assert_array_equal(st, ost)
+    np.testing.assert_array_equal(nxt, onxt)
+    np.testing.assert_array_equal(err, oerr)
