@@ -192,6 +192,25 @@ int sfm_triangulate_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
                         float min_dist, float max_dist, float max_proj_err, double* d_X,
                         uint8_t* d_rgb, uint8_t* d_mask, double* d_err);
 
+/* Device-resident hand-off from matching to triangulation: correspondence i is
+ * (prev key point d_matches[i].queryIdx, curr key point d_matches[i].trainIdx), i.e. the
+ * gather the reference does on the host after the cross-check (Source Files/
+ * feature_processing.cpp:164-165, :196-197) followed by its quadratic vector-to-matrix
+ * conversion (Header Files/common.h:47-57, called at Source Files/reconstruction.cpp:50-54),
+ * fused into the triangulation of Source Files/reconstruction.cpp:41-73.  d_matches and
+ * d_count are what sfm_match_pairs_dev wrote for one pair (d_count may be NULL: all `cap`
+ * entries are used); outputs are sized for `cap` and filled for the first
+ * min(*d_count, cap) entries.  A key point record starts with its (x, y) floats, records are
+ * `stride` bytes apart: 28 for an array of cv::KeyPoint, 8 for plain points. */
+int sfm_triangulate_matches_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
+                                const double* curr_pose, const double* R, const double* t,
+                                const sfm_dmatch* d_matches, const int32_t* d_count, int cap,
+                                const void* d_prev_keypts, size_t prev_keypt_stride,
+                                const void* d_curr_keypts, size_t curr_keypt_stride,
+                                const uint8_t* d_bgr, int img_w, int img_h, size_t img_stride,
+                                float min_dist, float max_dist, float max_proj_err, double* d_X,
+                                uint8_t* d_rgb, uint8_t* d_mask, double* d_err);
+
 #ifdef __cplusplus
 }
 #endif

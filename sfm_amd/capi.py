@@ -33,7 +33,7 @@ EXPORTS = [
     "sfm_knn2", "sfm_knn2_dev", "sfm_ratio_matches", "sfm_robust_matches",
     "sfm_match_pairs_dev", "sfm_match_pairs_workspace",
     "sfm_pyrlk", "sfm_pyrlk_batch_dev", "sfm_pyrlk_workspace",
-    "sfm_triangulate", "sfm_triangulate_dev",
+    "sfm_triangulate", "sfm_triangulate_dev", "sfm_triangulate_matches_dev",
 ]
 
 
@@ -284,3 +284,18 @@ class Context:
             _ptr(d_prev_pts), _ptr(d_curr_pts), C.c_int(n), _ptr(d_bgr), C.c_int(img_w),
             C.c_int(img_h), C.c_size_t(img_stride), C.c_float(min_dist), C.c_float(max_dist),
             C.c_float(max_proj_err), _ptr(d_X), _ptr(d_rgb), _ptr(d_mask), _ptr(d_err)))
+
+    def triangulate_matches_dev(self, K, prev_pose, curr_pose, R, t, d_matches, d_count, cap,
+                                d_prev_keypts, prev_stride, d_curr_keypts, curr_stride, d_bgr,
+                                img_w, img_h, img_stride, min_dist, max_dist, max_proj_err, d_X,
+                                d_rgb, d_mask, d_err=None):
+        """Triangulates the correspondences a match list (device, as sfm_match_pairs_dev wrote
+        it for one pair) selects from two device key point arrays."""
+        K, prev_pose, curr_pose, R, t = self._mats(K, prev_pose, curr_pose, R, t)
+        self.check(lib().sfm_triangulate_matches_dev(
+            self._h, _ptr(K), _ptr(prev_pose), _ptr(curr_pose), _ptr(R), _ptr(t),
+            _ptr(d_matches), _ptr(d_count), C.c_int(cap), _ptr(d_prev_keypts),
+            C.c_size_t(prev_stride), _ptr(d_curr_keypts), C.c_size_t(curr_stride), _ptr(d_bgr),
+            C.c_int(img_w), C.c_int(img_h), C.c_size_t(img_stride), C.c_float(min_dist),
+            C.c_float(max_dist), C.c_float(max_proj_err), _ptr(d_X), _ptr(d_rgb), _ptr(d_mask),
+            _ptr(d_err)))

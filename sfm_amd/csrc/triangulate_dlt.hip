@@ -38,8 +38,13 @@ struct TriArgs {
     double t[3];
     double Pc2[4];  // third row of K*[R|t]
     double fx, fy, cx, cy;
-    const float2* prev_pts;
+    const float2* prev_pts;     // point i of each image, or (matches != nullptr) ...
     const float2* curr_pts;
+    const sfm_dmatch* matches;  // ... point i = key point matches[i].queryIdx / .trainIdx
+    const uint8_t* kp_prev;     // key point records, `pt` (two floats) first, strides apart
+    const uint8_t* kp_curr;
+    size_t kp_prev_stride, kp_curr_stride;
+    const int32_t* count;       // device-side number of correspondences (nullptr: n)
     int n;
     const uint8_t* bgr;
     int img_w, img_h;
@@ -50,6 +55,27 @@ struct TriArgs {
     uint8_t* mask;
     double* err;
 };
+
+// Number of correspondences: the host's n, clipped by the device-side count when given.
+__device__ __forceinline__ int live_count(const TriArgs& a) {
+    if (!a.count) return a.n;
+    const int c = *a.count;
+    return c < a.n ? (c < 0 ? 0 : c) : a.n;
+}
+
+// Image points of correspondence i: straight from the point lists, or through the match
+// list from the two key point arrays (the gather the reference does on the host at
+// Source Files/feature_processing.cpp:164-165 and :196-197).
+__device__ __forceinline__ void load_points(const TriArgs& a, int i, float2& p1, float2& p2) {
+    if (a.matches) {
+        const sfm_dmatch m = a.matches[i];
+        p1 = *reinterpret_cast<const float2*>(a.kp_prev + (size_t)m.queryIdx * a.kp_prev_stride);
+        p2 = *reinterpret_cast<const float2*>(a.kp_curr + (size_t)m.trainIdx * a.kp_curr_stride);
+    } else {
+        p1 = a.prev_pts[i];
+        p2 = a.curr_pts[i];
+    }
+}
 
 // One Jacobi rotation of rows i, j of At (columns of A) and of Vt.
 template <int I, int J>
@@ -414,9 +440,9 @@ __device__ __forceinline__ void finish_point(const TriArgs& a, int i, const doub
 // Every point by one-sided Jacobi.
 __global__ __launch_bounds__(256) void triangulate_dlt_kernel(TriArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < a.n;
-    const float2 p1 = live ? a.prev_pts[i] : make_float2(0.f, 0.f);
-    const float2 p2 = live ? a.curr_pts[i] : make_float2(1.f, 1.f);
+    const bool live = i < live_count(a);
+    float2 p1 = make_float2(0.f, 0.f), p2 = make_float2(1.f, 1.f);
+    if (live) load_points(a, i, p1, p2);
     double At[4][4], v[4];
     build_system<false>(a, p1.x, p1.y, p2.x, p2.y, At);
     null_vector_jacobi(At, v);
@@ -432,9 +458,9 @@ constexpr int kListBins = 1024;
 __global__ __launch_bounds__(256) void triangulate_invit_kernel(TriArgs a, int* bin_count, int* list,
                                                                 int bin_cap) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < a.n;
-    const float2 p1 = live ? a.prev_pts[i] : make_float2(0.f, 0.f);
-    const float2 p2 = live ? a.curr_pts[i] : make_float2(1.f, 1.f);
+    const bool live = i < live_count(a);
+    float2 p1 = make_float2(0.f, 0.f), p2 = make_float2(1.f, 1.f);
+    if (live) load_points(a, i, p1, p2);
     double At[4][4], v[4];
     build_system<true>(a, p1.x, p1.y, p2.x, p2.y, At);
     const bool ok = null_vector_invit3(At, v);
@@ -463,8 +489,8 @@ __global__ __launch_bounds__(256) void triangulate_list_kernel(TriArgs a, const 
         const int k = k0 + threadIdx.x;
         const bool live = k < count;
         const int i = live ? mine[k] : mine[0];
-        const float2 p1 = a.prev_pts[i];
-        const float2 p2 = a.curr_pts[i];
+        float2 p1, p2;
+        load_points(a, i, p1, p2);
         double At[4][4], v[4];
         build_system<false>(a, p1.x, p1.y, p2.x, p2.y, At);
         const bool ok = null_vector_invit(At, v);
@@ -497,6 +523,32 @@ using namespace sfm;
 
 extern "C" {
 
+namespace {
+
+// Fills the camera part of the kernel arguments (reconstruction.cpp:68 and :13-14).
+void set_cameras(TriArgs& a, const double* K, const double* prev_pose, const double* curr_pose,
+                 const double* R, const double* t) {
+    mul_3x3_3x4(K, prev_pose, a.P1);
+    mul_3x3_3x4(K, curr_pose, a.P2);
+    double Rt[12], Pc[12];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) Rt[i * 4 + j] = R[i * 3 + j];
+        Rt[i * 4 + 3] = t[i];
+    }
+    mul_3x3_3x4(K, Rt, Pc);
+    for (int i = 0; i < 9; i++) a.R[i] = R[i];
+    for (int i = 0; i < 3; i++) a.t[i] = t[i];
+    for (int i = 0; i < 4; i++) a.Pc2[i] = Pc[8 + i];
+    a.fx = K[0];
+    a.fy = K[4];
+    a.cx = K[2];
+    a.cy = K[5];
+}
+
+int run_triangulation(sfm_ctx* ctx, TriArgs& a);
+
+}  // namespace
+
 int sfm_triangulate_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
                         const double* curr_pose, const double* R, const double* t,
                         const float* d_prev_pts, const float* d_curr_pts, int n,
@@ -512,21 +564,7 @@ int sfm_triangulate_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
         return set_error(ctx, SFM_E_INVALID, "bad colour image description");
     SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     TriArgs a{};
-    mul_3x3_3x4(K, prev_pose, a.P1);  // reconstruction.cpp:68
-    mul_3x3_3x4(K, curr_pose, a.P2);
-    double Rt[12], Pc[12];
-    for (int i = 0; i < 3; i++) {
-        for (int j = 0; j < 3; j++) Rt[i * 4 + j] = R[i * 3 + j];
-        Rt[i * 4 + 3] = t[i];
-    }
-    mul_3x3_3x4(K, Rt, Pc);  // reconstruction.cpp:13-14
-    for (int i = 0; i < 9; i++) a.R[i] = R[i];
-    for (int i = 0; i < 3; i++) a.t[i] = t[i];
-    for (int i = 0; i < 4; i++) a.Pc2[i] = Pc[8 + i];
-    a.fx = K[0];
-    a.fy = K[4];
-    a.cx = K[2];
-    a.cy = K[5];
+    set_cameras(a, K, prev_pose, curr_pose, R, t);
     a.prev_pts = reinterpret_cast<const float2*>(d_prev_pts);
     a.curr_pts = reinterpret_cast<const float2*>(d_curr_pts);
     a.n = n;
@@ -541,6 +579,57 @@ int sfm_triangulate_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
     a.rgb = d_rgb;
     a.mask = d_mask;
     a.err = d_err;
+    return run_triangulation(ctx, a);
+}
+
+int sfm_triangulate_matches_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
+                                const double* curr_pose, const double* R, const double* t,
+                                const sfm_dmatch* d_matches, const int32_t* d_count, int cap,
+                                const void* d_prev_keypts, size_t prev_keypt_stride,
+                                const void* d_curr_keypts, size_t curr_keypt_stride,
+                                const uint8_t* d_bgr, int img_w, int img_h, size_t img_stride,
+                                float min_dist, float max_dist, float max_proj_err, double* d_X,
+                                uint8_t* d_rgb, uint8_t* d_mask, double* d_err) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (cap < 0) return set_error(ctx, SFM_E_INVALID, "negative match capacity");
+    if (cap == 0) return SFM_OK;
+    if (!K || !prev_pose || !curr_pose || !R || !t || !d_matches || !d_prev_keypts || !d_curr_keypts ||
+        !d_X || !d_mask)
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (prev_keypt_stride < 8 || curr_keypt_stride < 8 || (prev_keypt_stride & 3) || (curr_keypt_stride & 3))
+        return set_error(ctx, SFM_E_INVALID, "key point stride must be a multiple of 4, at least 8");
+    if (d_bgr && (!d_rgb || img_w <= 0 || img_h <= 0 || img_stride < (size_t)img_w * 3))
+        return set_error(ctx, SFM_E_INVALID, "bad colour image description");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    TriArgs a{};
+    set_cameras(a, K, prev_pose, curr_pose, R, t);
+    a.matches = d_matches;
+    a.kp_prev = static_cast<const uint8_t*>(d_prev_keypts);
+    a.kp_curr = static_cast<const uint8_t*>(d_curr_keypts);
+    a.kp_prev_stride = prev_keypt_stride;
+    a.kp_curr_stride = curr_keypt_stride;
+    a.count = d_count;
+    a.n = cap;
+    a.bgr = d_bgr;
+    a.img_w = img_w;
+    a.img_h = img_h;
+    a.img_stride = img_stride;
+    a.min_dist = (double)min_dist;
+    a.max_dist = (double)max_dist;
+    a.max_err = (double)max_proj_err;
+    a.X = d_X;
+    a.rgb = d_rgb;
+    a.mask = d_mask;
+    a.err = d_err;
+    return run_triangulation(ctx, a);
+}
+
+}  // extern "C"
+
+namespace {
+
+int run_triangulation(sfm_ctx* ctx, TriArgs& a) {
+    const int n = a.n;
     static const bool force_jacobi = [] {
         const char* e = getenv("SFM_TRIANGULATE_JACOBI");
         return e && e[0] == '1';
@@ -577,6 +666,10 @@ int sfm_triangulate_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
     }
     return SFM_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int sfm_triangulate(sfm_ctx* ctx, const double* K, const double* prev_pose,
                     const double* curr_pose, const double* R, const double* t,

@@ -156,3 +156,64 @@ print("jacobi ok", rel.max())
                          timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "jacobi ok" in out.stdout
+
+
+def test_match_to_triangulation_stays_on_device(oracle):
+    """sfm_match_pairs_dev -> sfm_triangulate_matches_dev with nothing copied to the host in
+    between, against the reference's order of operations done with the oracle: robust
+    matches, key point gather through the match indices, triangulation.  Key points are
+    28-byte cv::KeyPoint-like records."""
+    import torch
+
+    from sfm_amd import capi, synth
+
+    ctx = capi.Context(0)
+    s = synth.triangulation_set(3000, seed=23)
+    n = len(s["p1"])
+    rng = np.random.default_rng(5)
+    # descriptors: frame 1 row j matches frame 0 row perm[j]; key points = the projections
+    d0 = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    perm = rng.permutation(n)
+    d1 = d0[perm].copy()
+    d1 ^= np.packbits(rng.random(size=(n, 256)) < 0.03, axis=1, bitorder="little")
+    fresh = rng.random(n) < 0.25
+    d1[fresh] = rng.integers(0, 256, size=(int(fresh.sum()), 32), dtype=np.uint8)
+    kp0 = np.zeros((n, 7), np.float32)          # pt.x pt.y size angle response octave class_id
+    kp1 = np.zeros((n, 7), np.float32)
+    kp0[:, :2] = s["p1"]
+    kp1[:, :2] = s["p2"][perm]
+    kp0[:, 2:] = 7.0
+    kp1[:, 2:] = -1.0
+
+    dev = torch.device("cuda:0")
+    d_desc = torch.from_numpy(np.stack([d0, d1])).to(dev)
+    d_pairs = torch.tensor([[0, 1]], dtype=torch.int32, device=dev)
+    cap = n
+    d_matches = torch.zeros((1, cap, 4), dtype=torch.int32, device=dev)
+    d_mc = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_kp0, d_kp1 = torch.from_numpy(kp0).to(dev), torch.from_numpy(kp1).to(dev)
+    d_X = torch.zeros((cap, 3), dtype=torch.float64, device=dev)
+    d_mask = torch.full((cap,), 7, dtype=torch.uint8, device=dev)
+    d_err = torch.zeros(cap, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    ctx.match_pairs_dev(capi.NORM_HAMMING, d_desc, 2, n * 32, n, None, 32, d_pairs, 1, 0.8,
+                        d_matches, cap, d_mc)
+    ctx.triangulate_matches_dev(s["K"], s["prev_pose"], s["curr_pose"], s["R"], s["t"], d_matches,
+                                d_mc, cap, d_kp0, 28, d_kp1, 28, None, 0, 0, 0, 1e-4, 250.0, 3.0,
+                                d_X, None, d_mask, d_err)
+    ctx.synchronize()
+
+    want_m = oracle.robust_matches(oracle.NORM_HAMMING, d0, d1, 0.8)
+    cnt = int(d_mc.item())
+    assert cnt == len(want_m) and cnt > 1500
+    p1 = kp0[want_m["queryIdx"], :2].copy()
+    p2 = kp1[want_m["trainIdx"], :2].copy()
+    oX, _, omask, oerr = oracle.triangulate(s["K"], s["prev_pose"], s["curr_pose"], s["R"], s["t"],
+                                            p1, p2)
+    X = d_X.cpu().numpy()[:cnt]
+    rel = np.linalg.norm(X - oX, axis=1) / np.linalg.norm(oX, axis=1)
+    assert rel.max() < 1e-9
+    clear = np.abs(oerr - 3.0) > 1e-6
+    assert np.array_equal(d_mask.cpu().numpy()[:cnt][clear], omask[clear])
+    assert (d_mask.cpu().numpy()[cnt:] == 7).all()   # entries past the count stay untouched
+    ctx.close()
