@@ -211,6 +211,33 @@ int sfm_triangulate_matches_dev(sfm_ctx* ctx, const double* K, const double* pre
                                 float min_dist, float max_dist, float max_proj_err, double* d_X,
                                 uint8_t* d_rgb, uint8_t* d_mask, double* d_err);
 
+/* ---- epipolar filter ------------------------------------------------------ */
+
+/* cv::findFundamentalMat(prevAligPts, currAligPts, inliersMask), the epipolar filter of
+ * DescriptorMatcher::findRobustMatches at Source Files/feature_processing.cpp:187-188:
+ * FM_RANSAC on 7-point samples with OpenCV's generator, sampling rules, error measure
+ * (larger squared distance to the two epipolar lines), adaptive iteration count and
+ * regimes (fewer than 7 points: nothing found; exactly 7: one direct solve, every point an
+ * inlier; 8 to 14: least median of squares; 15 and more: RANSAC).  The reference calls it
+ * with thresh 3, confidence 0.99, max_iters 1000; out-of-range thresh / confidence are
+ * replaced by those defaults as OpenCV does.  Points are interleaved (x, y) floats.
+ * mask[i] = 1 for inliers of the chosen matrix; it is all 0 when nothing is found (OpenCV
+ * leaves the caller's mask untouched then; the reference passes zeros).  F (may be NULL)
+ * receives the chosen 3x3 matrix, row-major.  The null space of each 7-point system is
+ * taken by elimination rather than by OpenCV's SVD; the candidate matrices agree with
+ * OpenCV's up to rounding. */
+int sfm_fundamental(sfm_ctx* ctx, const float* pts1, const float* pts2, int n, double thresh,
+                    double confidence, int max_iters, double* F, uint8_t* mask, int* found);
+/* The same for n_problems independent point sets on the device: set p starts at
+ * d_pts + p * problem_stride points and holds d_counts[p] (or count_uniform when d_counts is
+ * NULL) correspondences; d_F is [n_problems][9] (may be NULL), d_mask [n_problems]
+ * [problem_stride], d_found [n_problems]. */
+int sfm_fundamental_dev(sfm_ctx* ctx, const float* d_pts1, const float* d_pts2, size_t problem_stride,
+                        const int32_t* d_counts, int count_uniform, int n_problems, double thresh,
+                        double confidence, int max_iters, double* d_F, uint8_t* d_mask,
+                        int32_t* d_found);
+size_t sfm_fundamental_workspace(int n_problems, int max_iters);
+
 #ifdef __cplusplus
 }
 #endif

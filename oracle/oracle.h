@@ -12,7 +12,8 @@
  * OpenCV 4.x algorithms (modules/core/src/batch_distance.cpp,
  * modules/features2d/src/matchers.cpp, modules/video/src/lkpyramid.cpp,
  * modules/imgproc/src/pyramids.cpp, modules/calib3d/src/triangulate.cpp,
- * modules/calib3d/src/calibration.cpp) and are anchored on the reference's
+ * modules/calib3d/src/calibration.cpp, modules/calib3d/src/fundam.cpp,
+ * modules/calib3d/src/ptsetreg.cpp) and are anchored on the reference's
  * own call sites, cited per function as "Source Files/<file>:<line>".
  * They are checked against independently written NumPy vectors under
  * tests/golden/, not against OpenCV itself.
@@ -122,6 +123,27 @@ void orc_triangulate(const double* K, const double* prev_pose,
 /* Singular values (descending) and the right singular vector of the smallest
  * one for a row-major 4x4 matrix: the one-sided Jacobi of cv::SVD::compute. */
 void orc_svd4_null(const double* A, double* w, double* v);
+
+/* ---- epipolar filter ------------------------------------------------------ */
+
+/* cv::findFundamentalMat(points1, points2, mask) as called at
+ * Source Files/feature_processing.cpp:188 (FM_RANSAC, threshold 3, confidence 0.99, 1000
+ * iterations; OpenCV switches to LMedS below 15 points and to a direct 7-point solve at 7).
+ * Points are interleaved (x, y) floats.  mask gets `count` entries (untouched below 7 points,
+ * as in OpenCV).  F (nullable) receives the winning matrix, iters_run (nullable) the number
+ * of sampling iterations executed.  Returns 1 when a matrix was found.  The null space of
+ * the 7-point system is taken by elimination, not by OpenCV's SVD (see the source file). */
+int orc_find_fundamental(const float* m1, const float* m2, int count, double thresh,
+                         double confidence, int max_iters, double* F, uint8_t* mask,
+                         int* iters_run);
+/* run7Point: up to three 3x3 matrices (row-major, 9 doubles each) for seven correspondences;
+ * returns their number. */
+int orc_fm_7point(const float* m1, const float* m2, double* fmatrix);
+/* The index subsets the sampling loop draws, [max_iters][7]; returns how many were drawn. */
+int orc_fm_subsets(const float* m1, const float* m2, int count, int max_iters, int max_attempts,
+                   int32_t* idx);
+/* RANSACUpdateNumIters */
+int orc_ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
 
 #ifdef __cplusplus
 }

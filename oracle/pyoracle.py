@@ -174,6 +174,48 @@ def triangulate(K, prev_pose, curr_pose, R, t, prev_pts, curr_pts, bgr=None, min
     return X, rgb, mask, err
 
 
+def find_fundamental(p1, p2, thresh=3.0, confidence=0.99, max_iters=1000):
+    """Returns (found, F [3,3], mask [n] uint8, iterations run)."""
+    p1 = np.ascontiguousarray(p1, dtype=np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, dtype=np.float32).reshape(-1, 2)
+    n = p1.shape[0]
+    F = np.zeros(9)
+    mask = np.zeros(max(n, 1), np.uint8)
+    iters = C.c_int(0)
+    f = lib().orc_find_fundamental
+    f.restype = C.c_int
+    found = f(_p(p1), _p(p2), C.c_int(n), C.c_double(thresh), C.c_double(confidence),
+              C.c_int(max_iters), _p(F), _p(mask), C.byref(iters))
+    return bool(found), F.reshape(3, 3), mask[:n], iters.value
+
+
+def fm_7point(p1, p2):
+    """run7Point on seven correspondences: [k, 3, 3] matrices, k in 0..3."""
+    p1 = np.ascontiguousarray(p1, dtype=np.float32).reshape(7, 2)
+    p2 = np.ascontiguousarray(p2, dtype=np.float32).reshape(7, 2)
+    F = np.zeros(27)
+    f = lib().orc_fm_7point
+    f.restype = C.c_int
+    k = f(_p(p1), _p(p2), _p(F))
+    return F.reshape(3, 3, 3)[:max(k, 0)]
+
+
+def fm_subsets(p1, p2, max_iters=1000, max_attempts=10000):
+    p1 = np.ascontiguousarray(p1, dtype=np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, dtype=np.float32).reshape(-1, 2)
+    idx = np.zeros((max_iters, 7), np.int32)
+    f = lib().orc_fm_subsets
+    f.restype = C.c_int
+    k = f(_p(p1), _p(p2), C.c_int(p1.shape[0]), C.c_int(max_iters), C.c_int(max_attempts), _p(idx))
+    return idx[:k]
+
+
+def ransac_update_num_iters(p, ep, model_points, max_iters):
+    f = lib().orc_ransac_update_num_iters
+    f.restype = C.c_int
+    return f(C.c_double(p), C.c_double(ep), C.c_int(model_points), C.c_int(max_iters))
+
+
 def svd4_null(A):
     A = np.ascontiguousarray(A, dtype=np.float64).reshape(4, 4)
     w = np.zeros(4)

@@ -34,6 +34,7 @@ EXPORTS = [
     "sfm_match_pairs_dev", "sfm_match_pairs_workspace",
     "sfm_pyrlk", "sfm_pyrlk_batch_dev", "sfm_pyrlk_workspace",
     "sfm_triangulate", "sfm_triangulate_dev", "sfm_triangulate_matches_dev",
+    "sfm_fundamental", "sfm_fundamental_dev", "sfm_fundamental_workspace",
 ]
 
 
@@ -59,7 +60,7 @@ def lib():
         l.sfm_profile_kernel_name.restype = C.c_char_p
         l.sfm_ctx_destroy.restype = None
         l.sfm_ctx_destroy.argtypes = [C.c_void_p]
-        for name in ("sfm_match_pairs_workspace", "sfm_pyrlk_workspace"):
+        for name in ("sfm_match_pairs_workspace", "sfm_pyrlk_workspace", "sfm_fundamental_workspace"):
             if hasattr(l, name):
                 getattr(l, name).restype = C.c_size_t
         _lib = l
@@ -284,6 +285,33 @@ class Context:
             _ptr(d_prev_pts), _ptr(d_curr_pts), C.c_int(n), _ptr(d_bgr), C.c_int(img_w),
             C.c_int(img_h), C.c_size_t(img_stride), C.c_float(min_dist), C.c_float(max_dist),
             C.c_float(max_proj_err), _ptr(d_X), _ptr(d_rgb), _ptr(d_mask), _ptr(d_err)))
+
+    # ---- epipolar filter --------------------------------------------------
+    def fundamental(self, pts1, pts2, thresh=3.0, confidence=0.99, max_iters=1000):
+        """cv::findFundamentalMat(pts1, pts2, mask): returns (found, F [3,3], mask [n] uint8)."""
+        p1 = np.ascontiguousarray(pts1, dtype=np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(pts2, dtype=np.float32).reshape(-1, 2)
+        if p1.shape != p2.shape:
+            raise ValueError("point lists differ in length")
+        n = p1.shape[0]
+        F = np.zeros(9)
+        mask = np.zeros(max(n, 1), np.uint8)
+        found = C.c_int(0)
+        self.check(lib().sfm_fundamental(self._h, _ptr(p1), _ptr(p2), C.c_int(n), C.c_double(thresh),
+                                         C.c_double(confidence), C.c_int(max_iters), _ptr(F),
+                                         _ptr(mask), C.byref(found)))
+        return bool(found.value), F.reshape(3, 3), mask[:n]
+
+    def fundamental_dev(self, d_pts1, d_pts2, problem_stride, d_counts, count_uniform, n_problems,
+                        thresh, confidence, max_iters, d_F, d_mask, d_found):
+        self.check(lib().sfm_fundamental_dev(
+            self._h, _ptr(d_pts1), _ptr(d_pts2), C.c_size_t(problem_stride), _ptr(d_counts),
+            C.c_int(count_uniform), C.c_int(n_problems), C.c_double(thresh), C.c_double(confidence),
+            C.c_int(max_iters), _ptr(d_F), _ptr(d_mask), _ptr(d_found)))
+
+    @staticmethod
+    def fundamental_workspace(n_problems, max_iters):
+        return int(lib().sfm_fundamental_workspace(C.c_int(n_problems), C.c_int(max_iters)))
 
     def triangulate_matches_dev(self, K, prev_pose, curr_pose, R, t, d_matches, d_count, cap,
                                 d_prev_keypts, prev_stride, d_curr_keypts, curr_stride, d_bgr,

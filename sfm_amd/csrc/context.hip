@@ -210,7 +210,8 @@ const char* sfm_profile_kernel_name(int kernel_id) {
         "hamming_knn2_kernel", "hamming_pair_kernel", "ratio_cross_kernel", "merge_ratio_kernel", "knn_finalize_kernel", "pack_rows_kernel",
         "ratio_compact_kernel", "l2_candidates_kernel", "l2_rescore_kernel", "l2_pack_kernel",
         "lk_pad_level0_kernel", "lk_pyr_down_kernel", "lk_scharr_kernel", "lk_track_kernel",
-        "triangulate_dlt_kernel", "triangulate_list_kernel"};
+        "triangulate_dlt_kernel", "triangulate_list_kernel", "fm_subsets_kernel", "fm_solve_kernel",
+        "fm_score_kernel", "fm_select_kernel"};
     return kernel_id >= 0 && kernel_id < sfm::KID_COUNT ? names[kernel_id] : "";
 }
 

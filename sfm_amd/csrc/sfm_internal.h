@@ -30,6 +30,10 @@ enum KernelId {
     KID_LK_TRACK,
     KID_TRIANGULATE_DLT,
     KID_TRIANGULATE_LIST,
+    KID_FM_SUBSETS,
+    KID_FM_SOLVE,
+    KID_FM_SCORE,
+    KID_FM_SELECT,
     KID_COUNT
 };
 struct TimedLaunch {

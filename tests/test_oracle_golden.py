@@ -191,3 +191,49 @@ def test_triangulate_colour_lookup(oracle):
     px = np.clip(np.rint(g["p2"][:, 0].astype(np.float64)).astype(int), 0, 1279)
     py = np.clip(np.rint(g["p2"][:, 1].astype(np.float64)).astype(int), 0, 719)
     np.testing.assert_array_equal(rgb, img[py, px])
+
+
+def test_oracle_pieces_known_answers(oracle):
+    """The oracle itself (no GPU work): generator and iteration-count formula against values
+    computed by hand from their definitions, the 7-point solver against its defining
+    property."""
+    # cv::RNG: state = (uint32)state * 4164903690 + (state >> 32), seeded with 2^64 - 1
+    state = (1 << 64) - 1
+    want = []
+    for _ in range(21):
+        state = (state & 0xFFFFFFFF) * 4164903690 + (state >> 32)
+        want.append((state & 0xFFFFFFFF) % 1000)
+    p = np.stack([np.arange(1000) * 1.37 % 640, np.arange(1000) * 7.91 % 480], 1).astype(np.float32)
+    subs = oracle.fm_subsets(p, p[::-1].copy(), 3)
+    flat = [w for w in want]
+    # no repeated index among these draws, so the first subsets are the raw draws
+    assert len(set(flat[:7])) == 7
+    assert subs[0].tolist() == flat[:7]
+    # RANSACUpdateNumIters(0.99, 0.3, 7, 1000) = round(log(0.01) / log(1 - 0.7^7))
+    assert oracle.ransac_update_num_iters(0.99, 0.3, 7, 1000) == round(np.log(0.01) / np.log(1 - 0.7 ** 7))
+    assert oracle.ransac_update_num_iters(0.99, 0.9, 7, 1000) == 1000
+
+
+def test_oracle_fundamental_recovers_geometry(oracle):
+    """End to end on synthetic two-view data with known outliers: the mask keeps true
+    correspondences and rejects gross outliers; the 7-point matrices satisfy their defining
+    equations."""
+    from sfm_amd import synth
+
+    s = synth.triangulation_set(2000, seed=8)
+    rng = np.random.default_rng(9)
+    p1, p2 = s["p1"].copy(), s["p2"].copy()
+    bad = rng.random(2000) < 0.3
+    p2[bad] = np.stack([rng.uniform(0, 1280, bad.sum()), rng.uniform(0, 720, bad.sum())], 1)
+    found, F, mask, iters = oracle.find_fundamental(p1, p2)
+    assert found and 1 <= iters <= 1000
+    kept = mask.astype(bool)
+    assert (~bad)[kept].mean() > 0.95 and kept.sum() > 0.5 * (~bad).sum()
+    for Fk in oracle.fm_7point(p1[:7], p2[:7]):
+        h1 = np.c_[p1[:7].astype(np.float64), np.ones(7)]
+        h2 = np.c_[p2[:7].astype(np.float64), np.ones(7)]
+        assert np.abs(np.einsum("ni,ij,nj->n", h2, Fk, h1)).max() < 1e-9 * max(1.0, np.abs(Fk).max()) * 1e3
+        assert abs(np.linalg.det(Fk / np.abs(Fk).max())) < 1e-10
+    # fewer than 7 points: nothing found, mask untouched
+    found, _, mask, _ = oracle.find_fundamental(p1[:6], p2[:6])
+    assert not found and (mask == 0).all()
