@@ -238,6 +238,21 @@ int sfm_fundamental_dev(sfm_ctx* ctx, const float* d_pts1, const float* d_pts2, 
                         int32_t* d_found);
 size_t sfm_fundamental_workspace(int n_problems, int max_iters);
 
+/* The epipolar filter of findRobustMatches for many frame pairs, on the device, in place
+ * (Source Files/feature_processing.cpp:187-204 and :223 with useEpipolarFilter == true):
+ * gathers the matched key points of every pair (d_matches / d_match_counts as
+ * sfm_match_pairs_dev wrote them, key point arrays of frame f at d_keypts + f *
+ * frame_stride bytes, records keypt_stride bytes apart starting with (x, y) floats), runs
+ * cv::findFundamentalMat per pair and keeps the inlier matches in order, updating the
+ * counts.  A pair with fewer than 7 matches keeps none, as in the reference (OpenCV finds no
+ * matrix and the zero-initialised mask drops everything).  d_mask (may be NULL) receives the
+ * [n_pairs][cap] inlier masks of the unfiltered lists. */
+int sfm_epipolar_filter_pairs_dev(sfm_ctx* ctx, const void* d_keypts, size_t frame_stride,
+                                  size_t keypt_stride, const int32_t* d_pairs, int n_pairs,
+                                  sfm_dmatch* d_matches, int cap, int32_t* d_match_counts, double thresh,
+                                  double confidence, int max_iters, uint8_t* d_mask);
+size_t sfm_epipolar_filter_pairs_workspace(int n_pairs, int cap, int max_iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,9 +174,10 @@ public:
     int normType; /* SFM_NORM_* */
     Handle handle;
 
-    /* Optional epipolar filter (points -> inlier mask), the step at
-     * Source Files/feature_processing.cpp:187-188 that stays with the caller.
-     * With OpenCV present it defaults to cv::findFundamentalMat. */
+    /* Epipolar filter (points -> inlier mask), the step at
+     * Source Files/feature_processing.cpp:187-188.  Defaults to the library's
+     * restatement of cv::findFundamentalMat (RANSAC, 3 px, 0.99) on the GPU;
+     * assign another callable (cv::findFundamentalMat itself, say) to replace it. */
     std::function<void(const std::vector<cvx::Point2f>&, const std::vector<cvx::Point2f>&, std::vector<uint8_t>&)>
         epipolarFilter;
 
@@ -190,11 +191,18 @@ public:
         else if (method == "BRUTEFORCE_SL2") normType = SFM_NORM_L2SQR;
         else if (method == "FLANNBASED") raise("FLANNBASED matching is approximate and not provided by sfm_hip");
         else normType = SFM_NORM_L2;
-#ifdef SFM_ADAPTER_HAVE_OPENCV
-        epipolarFilter = [](const std::vector<cv::Point2f>& a, const std::vector<cv::Point2f>& b, std::vector<uint8_t>& m) {
-            cv::findFundamentalMat(a, b, m);
+        static_assert(sizeof(cvx::Point2f) == 2 * sizeof(float), "Point2f must be two packed floats");
+        epipolarFilter = [h](const std::vector<cvx::Point2f>& a, const std::vector<cvx::Point2f>& b,
+                             std::vector<uint8_t>& m) {
+            if (a.size() != b.size()) raise("epipolar filter: point lists differ in length");
+            m.assign(a.size(), 0);
+            double F[9];
+            int found = 0;
+            h.check(sfm_fundamental(h.get(), reinterpret_cast<const float*>(a.data()),
+                                     reinterpret_cast<const float*>(b.data()), int(a.size()), 3.0, 0.99, 1000, F,
+                                     m.data(), &found),
+                     "sfm_fundamental");
         };
-#endif
     }
 
     /* Source Files/feature_processing.cpp:118-130. */

@@ -35,6 +35,7 @@ EXPORTS = [
     "sfm_pyrlk", "sfm_pyrlk_batch_dev", "sfm_pyrlk_workspace",
     "sfm_triangulate", "sfm_triangulate_dev", "sfm_triangulate_matches_dev",
     "sfm_fundamental", "sfm_fundamental_dev", "sfm_fundamental_workspace",
+    "sfm_epipolar_filter_pairs_dev", "sfm_epipolar_filter_pairs_workspace",
 ]
 
 
@@ -60,7 +61,8 @@ def lib():
         l.sfm_profile_kernel_name.restype = C.c_char_p
         l.sfm_ctx_destroy.restype = None
         l.sfm_ctx_destroy.argtypes = [C.c_void_p]
-        for name in ("sfm_match_pairs_workspace", "sfm_pyrlk_workspace", "sfm_fundamental_workspace"):
+        for name in ("sfm_match_pairs_workspace", "sfm_pyrlk_workspace", "sfm_fundamental_workspace",
+                     "sfm_epipolar_filter_pairs_workspace"):
             if hasattr(l, name):
                 getattr(l, name).restype = C.c_size_t
         _lib = l
@@ -308,6 +310,19 @@ class Context:
             self._h, _ptr(d_pts1), _ptr(d_pts2), C.c_size_t(problem_stride), _ptr(d_counts),
             C.c_int(count_uniform), C.c_int(n_problems), C.c_double(thresh), C.c_double(confidence),
             C.c_int(max_iters), _ptr(d_F), _ptr(d_mask), _ptr(d_found)))
+
+    def epipolar_filter_pairs_dev(self, d_keypts, frame_stride, keypt_stride, d_pairs, n_pairs,
+                                  d_matches, cap, d_match_counts, thresh=3.0, confidence=0.99,
+                                  max_iters=1000, d_mask=None):
+        self.check(lib().sfm_epipolar_filter_pairs_dev(
+            self._h, _ptr(d_keypts), C.c_size_t(frame_stride), C.c_size_t(keypt_stride), _ptr(d_pairs),
+            C.c_int(n_pairs), _ptr(d_matches), C.c_int(cap), _ptr(d_match_counts), C.c_double(thresh),
+            C.c_double(confidence), C.c_int(max_iters), _ptr(d_mask)))
+
+    @staticmethod
+    def epipolar_filter_pairs_workspace(n_pairs, cap, max_iters=1000):
+        return int(lib().sfm_epipolar_filter_pairs_workspace(C.c_int(n_pairs), C.c_int(cap),
+                                                             C.c_int(max_iters)))
 
     @staticmethod
     def fundamental_workspace(n_problems, max_iters):

@@ -521,6 +521,59 @@ __global__ __launch_bounds__(256) void fm_mask_kernel(FmArgs a) {
     }
 }
 
+// Aligned point lists of every pair: pts[p][i] = key point of matches[p][i]
+// (Source Files/feature_processing.cpp:164-165).
+__global__ void fm_gather_kernel(const sfm_dmatch* __restrict__ matches, const int32_t* __restrict__ counts,
+                                 int cap, const uint8_t* __restrict__ keypts, size_t frame_stride,
+                                 size_t keypt_stride, const int32_t* __restrict__ pairs,
+                                 float2* __restrict__ pts1, float2* __restrict__ pts2) {
+    const int p = blockIdx.y;
+    const int n = min(counts[p], cap);
+    const uint8_t* k1 = keypts + (size_t)pairs[2 * p] * frame_stride;
+    const uint8_t* k2 = keypts + (size_t)pairs[2 * p + 1] * frame_stride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const sfm_dmatch m = matches[(size_t)p * cap + i];
+        pts1[(size_t)p * cap + i] = *reinterpret_cast<const float2*>(k1 + (size_t)m.queryIdx * keypt_stride);
+        pts2[(size_t)p * cap + i] = *reinterpret_cast<const float2*>(k2 + (size_t)m.trainIdx * keypt_stride);
+    }
+}
+
+// Keeps the matches whose mask entry is set, in order (Source Files/
+// feature_processing.cpp:193-204 with useEpipolarFilter == true, then :223).  One workgroup
+// per pair; in place: an element is only ever moved to a lower index, and a whole chunk is
+// read before any of it is written.
+__global__ __launch_bounds__(1024) void fm_compact_kernel(sfm_dmatch* __restrict__ matches,
+                                                          int32_t* __restrict__ counts, int cap,
+                                                          const uint8_t* __restrict__ mask) {
+    __shared__ int wave_count[16];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(counts[p], cap);
+    sfm_dmatch* mine = matches + (size_t)p * cap;
+    const uint8_t* keep = mask + (size_t)p * cap;
+    int running = 0;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        const bool ok = i < n && keep[i] != 0;
+        sfm_dmatch m{};
+        if (ok) m = mine[i];
+        const unsigned long long ballot = __ballot(ok);
+        const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_count[wave] = __popcll(ballot);
+        __syncthreads();  // also: every read of this chunk is done
+        int offset = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = wave_count[w];
+            offset += w < wave ? c : 0;
+            total += c;
+        }
+        if (ok) mine[running + offset + prefix] = m;
+        running += total;
+        __syncthreads();
+    }
+    if (tid == 0) counts[p] = running;
+}
+
 struct FmBuffers {
     int32_t* subsets;
     int32_t* n_drawn;
@@ -540,6 +593,35 @@ FmBuffers carve_fm(Carver& c, int n_problems, int max_iters) {
     b.scores = c.take<float>(pi * 3);
     b.n_drawn = c.take<int32_t>((size_t)n_problems);
     return b;
+}
+
+// The five steps for the point sets described by `a`.
+int run_fm(sfm_ctx* ctx, const FmArgs& a) {
+    const int n_problems = a.n_problems, max_iters = a.max_iters;
+    {
+        KernelTimer timer(ctx, KID_FM_SUBSETS);
+        hipLaunchKernelGGL(fm_subsets_kernel, dim3(n_problems), dim3(64), 0, ctx->stream, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    {
+        KernelTimer timer(ctx, KID_FM_SOLVE);
+        hipLaunchKernelGGL(fm_solve_kernel, dim3((max_iters + 63) / 64, n_problems), dim3(64), 0,
+                           ctx->stream, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    {
+        KernelTimer timer(ctx, KID_FM_SCORE);
+        hipLaunchKernelGGL(fm_score_kernel, dim3(max_iters, n_problems), dim3(64), 0, ctx->stream, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    {
+        KernelTimer timer(ctx, KID_FM_SELECT);
+        hipLaunchKernelGGL(fm_select_kernel, dim3((n_problems + 63) / 64), dim3(64), 0, ctx->stream, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(fm_mask_kernel, dim3(n_problems), dim3(256), 0, ctx->stream, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return SFM_OK;
 }
 
 }  // namespace
@@ -595,30 +677,7 @@ int sfm_fundamental_dev(sfm_ctx* ctx, const float* d_pts1, const float* d_pts2, 
     a.F = d_F;
     a.mask = d_mask;
     a.found = d_found;
-    {
-        KernelTimer timer(ctx, KID_FM_SUBSETS);
-        hipLaunchKernelGGL(fm_subsets_kernel, dim3(n_problems), dim3(64), 0, ctx->stream, a);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
-    }
-    {
-        KernelTimer timer(ctx, KID_FM_SOLVE);
-        hipLaunchKernelGGL(fm_solve_kernel, dim3((max_iters + 63) / 64, n_problems), dim3(64), 0,
-                           ctx->stream, a);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
-    }
-    {
-        KernelTimer timer(ctx, KID_FM_SCORE);
-        hipLaunchKernelGGL(fm_score_kernel, dim3(max_iters, n_problems), dim3(64), 0, ctx->stream, a);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
-    }
-    {
-        KernelTimer timer(ctx, KID_FM_SELECT);
-        hipLaunchKernelGGL(fm_select_kernel, dim3((n_problems + 63) / 64), dim3(64), 0, ctx->stream, a);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
-        hipLaunchKernelGGL(fm_mask_kernel, dim3(n_problems), dim3(256), 0, ctx->stream, a);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
-    }
-    return SFM_OK;
+    return run_fm(ctx, a);
 }
 
 int sfm_fundamental(sfm_ctx* ctx, const float* pts1, const float* pts2, int n, double thresh,
@@ -653,6 +712,76 @@ int sfm_fundamental(sfm_ctx* ctx, const float* pts1, const float* pts2, int n, d
     SFM_HIP_CHECK(ctx, hipMemcpyAsync(&h_found, df, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (found) *found = h_found;
+    return SFM_OK;
+}
+
+size_t sfm_epipolar_filter_pairs_workspace(int n_pairs, int cap, int max_iters) {
+    if (n_pairs <= 0 || cap <= 0 || max_iters <= 0) return 0;
+    Carver c(nullptr);
+    c.take<float2>((size_t)n_pairs * cap);
+    c.take<float2>((size_t)n_pairs * cap);
+    c.take<uint8_t>((size_t)n_pairs * cap);
+    c.take<int32_t>((size_t)n_pairs);
+    return c.total() + sfm_fundamental_workspace(n_pairs, max_iters);
+}
+
+int sfm_epipolar_filter_pairs_dev(sfm_ctx* ctx, const void* d_keypts, size_t frame_stride,
+                                  size_t keypt_stride, const int32_t* d_pairs, int n_pairs,
+                                  sfm_dmatch* d_matches, int cap, int32_t* d_match_counts, double thresh,
+                                  double confidence, int max_iters, uint8_t* d_mask) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (n_pairs < 0 || cap < 0 || max_iters < 1 || max_iters > 100000)
+        return set_error(ctx, SFM_E_INVALID, "bad pair, capacity or iteration count");
+    if (n_pairs == 0 || cap == 0) return SFM_OK;
+    if (!d_keypts || !d_pairs || !d_matches || !d_match_counts)
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (keypt_stride < 8 || (keypt_stride & 3) || (frame_stride & 3))
+        return set_error(ctx, SFM_E_INVALID, "key point strides must be multiples of 4, at least 8");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (thresh <= 0) thresh = 3;
+    if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
+    // one workspace: the point lists and the mask in front, the RANSAC buffers behind them
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, sfm_epipolar_filter_pairs_workspace(n_pairs, cap, max_iters), &ws));
+    Carver c(ws);
+    float2* pts1 = c.take<float2>((size_t)n_pairs * cap);
+    float2* pts2 = c.take<float2>((size_t)n_pairs * cap);
+    uint8_t* mask = c.take<uint8_t>((size_t)n_pairs * cap);
+    int32_t* found = c.take<int32_t>((size_t)n_pairs);
+    const FmBuffers b = carve_fm(c, n_pairs, max_iters);
+    {
+        KernelTimer timer(ctx, KID_FM_SELECT);
+        hipLaunchKernelGGL(fm_gather_kernel, dim3((cap + 255) / 256, n_pairs), dim3(256), 0, ctx->stream,
+                           d_matches, d_match_counts, cap, static_cast<const uint8_t*>(d_keypts), frame_stride,
+                           keypt_stride, d_pairs, pts1, pts2);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    FmArgs a{};
+    a.pts1 = pts1;
+    a.pts2 = pts2;
+    a.stride = (size_t)cap;
+    a.counts = d_match_counts;
+    a.n_problems = n_pairs;
+    a.max_iters = max_iters;
+    a.thresh = thresh;
+    a.confidence = confidence;
+    a.subsets = b.subsets;
+    a.n_drawn = b.n_drawn;
+    a.models = b.models;
+    a.n_models = b.n_models;
+    a.scores = b.scores;
+    a.best = b.best;
+    a.F = nullptr;
+    a.mask = mask;
+    a.found = found;
+    SFM_RETURN_IF(run_fm(ctx, a));
+    if (d_mask)
+        SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_mask, mask, (size_t)n_pairs * cap, hipMemcpyDeviceToDevice,
+                                          ctx->stream));
+    KernelTimer timer(ctx, KID_FM_SELECT);
+    hipLaunchKernelGGL(fm_compact_kernel, dim3(n_pairs), dim3(1024), 0, ctx->stream, d_matches,
+                       d_match_counts, cap, mask);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
 }
 

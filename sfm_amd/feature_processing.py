@@ -56,19 +56,18 @@ class DescriptorMatcher:
 
     def findRobustMatches(self, prevKeyPts, currKeyPts, prevDesc, currDesc,
                           useEpipolarFilter=False):
-        """feature_processing.cpp:144-226 without the fundamental-matrix RANSAC step.
+        """feature_processing.cpp:144-226.
 
         Returns (prevAligPts, currAligPts, matches, prevPtsToKeyIdx, currPtsToKeyIdx), i.e.
-        what the reference leaves in its five output vectors when it is called
-        with useEpipolarFilter == false (all cross-checked matches survive).
+        what the reference leaves in its five output vectors: the cross-checked matches, and
+        with useEpipolarFilter only those cv::findFundamentalMat marks as inliers (:187-204).
         """
-        if useEpipolarFilter:
-            raise capi.SfmError("the fundamental-matrix RANSAC filter "
-                                "(feature_processing.cpp:187-204) is outside this library; "
-                                "call with useEpipolarFilter=False and filter the result")
         prevKeyPts = np.asarray(prevKeyPts, dtype=np.float32).reshape(-1, 2)
         currKeyPts = np.asarray(currKeyPts, dtype=np.float32).reshape(-1, 2)
         m = self.ctx.robust_matches(self.norm, prevDesc, currDesc, float(self.m_ratioThreshold))
+        if useEpipolarFilter and len(m):
+            _, _, mask = self.ctx.fundamental(prevKeyPts[m["queryIdx"]], currKeyPts[m["trainIdx"]])
+            m = m[mask.astype(bool)]
         prev_idx = m["queryIdx"].astype(np.int32)
         curr_idx = m["trainIdx"].astype(np.int32)
         return prevKeyPts[prev_idx], currKeyPts[curr_idx], m, prev_idx, curr_idx

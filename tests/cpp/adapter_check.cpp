@@ -54,14 +54,21 @@ static int run_match(const char* in, const char* out) {
     r.raw(prevDesc.data, size_t(n_prev) * prevDesc.step);
     r.raw(currDesc.data, size_t(n_curr) * currDesc.step);
     std::vector<cvx::KeyPoint> prevKp, currKp;
-    for (int i = 0; i < n_prev; ++i) prevKp.emplace_back(float(i) + 0.25f, float(2 * i), 7.f);
-    for (int i = 0; i < n_curr; ++i) currKp.emplace_back(float(3 * i), float(i) + 0.5f, 7.f);
+    if (use_filter == 2) {  // key point positions follow the descriptors: the library's own filter runs on them
+        std::vector<float> xy(size_t(2) * size_t(n_prev + n_curr));
+        r.raw(xy.data(), xy.size() * 4);
+        for (int i = 0; i < n_prev; ++i) prevKp.emplace_back(xy[2 * i], xy[2 * i + 1], 7.f);
+        for (int i = n_prev; i < n_prev + n_curr; ++i) currKp.emplace_back(xy[2 * i], xy[2 * i + 1], 7.f);
+    } else {
+        for (int i = 0; i < n_prev; ++i) prevKp.emplace_back(float(i) + 0.25f, float(2 * i), 7.f);
+        for (int i = 0; i < n_curr; ++i) currKp.emplace_back(float(3 * i), float(i) + 0.5f, 7.f);
+    }
 
     const char* method = norm == SFM_NORM_HAMMING ? "BruteForce_Hamming" : norm == SFM_NORM_L2SQR ? "bruteforce_sl2" : "BruteForce";
     sfm_hip::DescriptorMatcher matcher(method, ratio);
     sfm_hip::DescriptorMatcher byValue = matcher;  // the reference passes it by value
-    if (use_filter) {
-        // stand-in for cv::findFundamentalMat: drops every third match
+    if (use_filter == 1) {
+        // a caller's own filter in place of the default: drops every third match
         byValue.epipolarFilter = [](const std::vector<cvx::Point2f>& a, const std::vector<cvx::Point2f>&, std::vector<uint8_t>& m) {
             m.assign(a.size(), 1);
             for (size_t i = 0; i < m.size(); i += 3) m[i] = 0;
@@ -191,7 +198,9 @@ static int run_errors() {
         // identical, distinct rows give cross-checked matches, so the filter is reached
         for (int i = 0; i < 8; ++i)
             for (int j = 0; j < 32; ++j) u8.data[i * 32 + j] = uint8_t(i == (j & 7) ? 0xFF : 0);
-        ham.findRobustMatches(kp, kp, u8, u8, a, b, m, ia, ib, cvx::Mat(), cvx::Mat(), true);
+        sfm_hip::DescriptorMatcher noFilter = ham;
+        noFilter.epipolarFilter = nullptr;
+        noFilter.findRobustMatches(kp, kp, u8, u8, a, b, m, ia, ib, cvx::Mat(), cvx::Mat(), true);
     });
     sfm_hip::OptFlow of(cvx::TermCriteria(3, 30, 0.01), 21, 3, 10.f, 100u, 0.01f, 10.f, 30u);
     bad += must_raise("colour image into computeFlow", [&] {

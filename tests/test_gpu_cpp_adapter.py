@@ -61,7 +61,7 @@ def test_find_robust_matches(oracle, tmp_path, norm, use_filter):
         idx, dist = oracle.knn2_l2(prev, curr, squared=(norm == 2))
     want_fwd = oracle.ratio_filter(idx, dist, len(curr), ratio)
     want = oracle.robust_matches(norm, prev, curr, ratio)
-    if use_filter:  # the stand-in filter drops matches 0, 3, 6, ...
+    if use_filter:  # the caller's filter of the check program drops matches 0, 3, 6, ...
         want = want[np.arange(len(want)) % 3 != 0]
 
     n = out.i32()
@@ -131,3 +131,34 @@ def test_misuse_raises():
     assert os.path.exists(CHECK)
     res = subprocess.run([CHECK, "errors"], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
+
+
+def test_find_robust_matches_default_epipolar_filter(oracle, tmp_path):
+    """useEpipolarFilter = true with the adapter's default filter (sfm_fundamental): the
+    matches kept are those the oracle's findFundamentalMat marks, in order."""
+    n = 1400
+    s = synth.triangulation_set(n, seed=61)
+    rng = np.random.default_rng(62)
+    prev = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    perm = rng.permutation(n)
+    curr = prev[perm].copy()
+    curr ^= np.packbits(rng.random(size=(n, 256)) < 0.04, axis=1, bitorder="little")
+    kp0, kp1 = s["p1"].astype(np.float32), s["p2"][perm].astype(np.float32)
+    wrong = rng.random(n) < 0.2
+    kp1[wrong] = np.stack([rng.uniform(0, 1280, wrong.sum()), rng.uniform(0, 720, wrong.sum())], 1).astype(np.float32)
+    payload = struct.pack("<iiiifi", 0, n, n, 32, 0.8, 2)
+    out = Cursor(run("match", payload + prev.tobytes() + curr.tobytes() + kp0.tobytes() + kp1.tobytes(), tmp_path))
+
+    want = oracle.robust_matches(0, prev, curr, 0.8)
+    _, _, mask, _ = oracle.find_fundamental(kp0[want["queryIdx"]], kp1[want["trainIdx"]])
+    want = want[mask.astype(bool)]
+    out.arr(DMATCH, out.i32())  # forward ratio matches, covered above
+    matches = out.arr(DMATCH, out.i32())
+    assert 300 < len(want) and matches.tobytes() == want.tobytes()
+    k = out.i32()
+    assert k == len(want)
+    assert np.array_equal(out.arr("<f4", 2 * k).reshape(k, 2), kp0[want["queryIdx"]])
+    assert np.array_equal(out.arr("<f4", 2 * k).reshape(k, 2), kp1[want["trainIdx"]])
+    assert out.i32() == k
+    assert np.array_equal(out.arr("<i4", k), want["queryIdx"])
+    assert np.array_equal(out.arr("<i4", k), want["trainIdx"])

@@ -118,3 +118,87 @@ def test_batched_problems_with_device_counts(ctx, oracle):
             assert bool(founds[k]) == ofound
             np.testing.assert_array_equal(masks[k, :n], omask)
         assert (masks[k, n:] == 9).all()  # nothing written past a problem's count
+
+
+def test_epipolar_filter_pairs_in_place(ctx, oracle):
+    """sfm_match_pairs_dev followed by sfm_epipolar_filter_pairs_dev on the device, against
+    the reference's order of operations done with the oracle: robust matches, key point
+    gather, findFundamentalMat, keep the inliers in order
+    (Source Files/feature_processing.cpp:148-204, useEpipolarFilter == true)."""
+    import torch
+
+    from sfm_amd import capi, synth
+
+    n, n_frames = 1500, 3
+    s = synth.triangulation_set(n, seed=41)
+    rng = np.random.default_rng(42)
+    base = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    descs, kps = [], []
+    views = [s["p1"], s["p2"], s["p2"] + np.float32(3.0)]
+    for f in range(n_frames):
+        perm = rng.permutation(n)
+        d = base[perm].copy()
+        d ^= np.packbits(rng.random(size=(n, 256)) < 0.03, axis=1, bitorder="little")
+        fresh = rng.random(n) < 0.3
+        d[fresh] = rng.integers(0, 256, size=(int(fresh.sum()), 32), dtype=np.uint8)
+        kp = np.zeros((n, 7), np.float32)       # 28-byte cv::KeyPoint-like records
+        kp[:, :2] = views[f][perm]
+        kp[fresh, :2] = np.stack([rng.uniform(0, 1280, fresh.sum()), rng.uniform(0, 720, fresh.sum())], 1)
+        descs.append(d)
+        kps.append(kp)
+    counts = np.array([n, n - 200, 5], np.int32)     # the last frame yields (almost) no matches
+    pairs = np.array([[0, 1], [1, 0], [0, 2], [1, 2]], np.int32)
+    dev = torch.device("cuda:0")
+    d_desc = torch.from_numpy(np.stack(descs)).to(dev)
+    d_kp = torch.from_numpy(np.stack(kps)).to(dev)
+    d_counts = torch.from_numpy(counts).to(dev)
+    d_pairs = torch.from_numpy(pairs).to(dev)
+    P, cap = len(pairs), n
+    d_matches = torch.zeros((P, cap, 4), dtype=torch.int32, device=dev)
+    d_mc = torch.zeros(P, dtype=torch.int32, device=dev)
+    d_mask = torch.zeros((P, cap), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.match_pairs_dev(capi.NORM_HAMMING, d_desc, n_frames, n * 32, n, d_counts, 32, d_pairs, P, 0.8,
+                        d_matches, cap, d_mc)
+    ctx.epipolar_filter_pairs_dev(d_kp, n * 28, 28, d_pairs, P, d_matches, cap, d_mc, d_mask=d_mask)
+    ctx.synchronize()
+    mc = d_mc.cpu().numpy()
+    m = d_matches.cpu().numpy().view(capi.DMATCH_DTYPE).reshape(P, cap)
+    kept_total = 0
+    for p, (a, b) in enumerate(pairs):
+        want = oracle.robust_matches(oracle.NORM_HAMMING, descs[a][: counts[a]], descs[b][: counts[b]], 0.8)
+        p1 = kps[a][want["queryIdx"], :2].copy()
+        p2 = kps[b][want["trainIdx"], :2].copy()
+        if len(want) >= 7:
+            _, _, omask, _ = oracle.find_fundamental(p1, p2)
+        else:
+            omask = np.zeros(len(want), np.uint8)   # no matrix: the zero mask drops every match
+        want = want[omask.astype(bool)]
+        assert mc[p] == len(want), (a, b)
+        assert m[p][: mc[p]].tobytes() == want.tobytes(), (a, b)
+        kept_total += len(want)
+    assert kept_total > 500 and mc[2] == 0
+
+
+def test_python_wrapper_epipolar_filter(ctx, oracle):
+    """DescriptorMatcher.findRobustMatches(useEpipolarFilter=True) end to end."""
+    from sfm_amd import DescriptorMatcher, synth
+
+    n = 1200
+    s = synth.triangulation_set(n, seed=51)
+    rng = np.random.default_rng(52)
+    d0 = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    perm = rng.permutation(n)
+    d1 = d0[perm].copy()
+    d1 ^= np.packbits(rng.random(size=(n, 256)) < 0.04, axis=1, bitorder="little")
+    kp0, kp1 = s["p1"], s["p2"][perm].copy()
+    wrong = rng.random(n) < 0.15
+    kp1[wrong] = np.stack([rng.uniform(0, 1280, wrong.sum()), rng.uniform(0, 720, wrong.sum())], 1)
+    m = DescriptorMatcher("BruteForce_Hamming", 0.8, ctx=ctx)
+    pp, cp, matches, pi, ci = m.findRobustMatches(kp0, kp1, d0, d1, useEpipolarFilter=True)
+    want = oracle.robust_matches(oracle.NORM_HAMMING, d0, d1, 0.8)
+    _, _, omask, _ = oracle.find_fundamental(kp0[want["queryIdx"]], kp1[want["trainIdx"]])
+    want = want[omask.astype(bool)]
+    assert len(want) > 300 and matches.tobytes() == want.tobytes()
+    assert np.array_equal(pi, want["queryIdx"]) and np.array_equal(ci, want["trainIdx"])
+    assert np.array_equal(pp, kp0[want["queryIdx"]]) and np.array_equal(cp, kp1[want["trainIdx"]])
