@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="framepair", choices=["framepair", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="framepair", choices=["framepair", "c3", "c4", "c5", "f1"])
     ap.add_argument("--pairs", type=int, default=32, help="frame pairs per rank and step")
     ap.add_argument("--frames", type=int, default=512, help="c5: frames in the window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -467,10 +467,131 @@ def run_c5(args, rank, world, local):
     return out
 
 
+# --------------------------------------------------------------------------- f1 epipolar filter
+F64_VALU_PEAK_TLANEOPS = 39.3   # 256 CU x 4 SIMD x 16 fp64 lanes x 2.4 GHz
+FM_ERROR_OPS = 34               # fp64 lane-ops of one symmetric epipolar error
+
+
+def f1_inputs(P, seed):
+    """2P frames of KPS key points: frame 2p+1 re-observes 70 % of frame 2p's features (second
+    view of the same 3D points, 0.5 px noise) of which 20 % sit at a wrong place."""
+    from sfm_amd import synth
+
+    rng = np.random.default_rng(seed)
+    desc = np.empty((2 * P, KPS, DESC_BYTES), np.uint8)
+    kps = np.zeros((2 * P, KPS, 7), np.float32)   # 28-byte records like cv::KeyPoint, .pt first
+    for p in range(P):
+        s = synth.triangulation_set(KPS, seed=seed + 31 * p, outliers=0.0)
+        a = rng.integers(0, 256, size=(KPS, DESC_BYTES), dtype=np.uint8)
+        perm = rng.permutation(KPS)
+        b = a[perm].copy()
+        b ^= np.packbits(rng.random(size=(KPS, 8 * DESC_BYTES)) < 0.05, axis=1, bitorder="little")
+        fresh = rng.random(KPS) < 0.3
+        b[fresh] = rng.integers(0, 256, size=(int(fresh.sum()), DESC_BYTES), dtype=np.uint8)
+        kb = s["p2"][perm].copy()
+        wrong = rng.random(KPS) < 0.2
+        kb[wrong] = np.stack([rng.uniform(0, LK_W, wrong.sum()), rng.uniform(0, LK_H, wrong.sum())], 1)
+        desc[2 * p], desc[2 * p + 1] = a, b
+        kps[2 * p, :, :2], kps[2 * p + 1, :, :2] = s["p1"], kb
+    return desc, kps
+
+
+def run_f1(args, rank, world, local):
+    """The epipolar filter of findRobustMatches (feature_processing.cpp:187-204) on the match
+    lists of P frame pairs, device-resident: key point gather, findFundamentalMat (RANSAC),
+    ordered compaction of the inliers."""
+    import torch
+
+    from sfm_amd import capi
+
+    dev = torch.device("cuda", local)
+    P = args.pairs
+    ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
+    desc, kps = f1_inputs(P, seed=777 + rank)
+    pairs = np.stack([2 * np.arange(P), 2 * np.arange(P) + 1], 1).astype(np.int32)
+    d_desc, d_kps = torch.from_numpy(desc).to(dev), torch.from_numpy(kps).to(dev)
+    d_pairs = torch.from_numpy(pairs).to(dev)
+    cap = KPS
+    d_m0 = torch.empty((P, cap, 4), dtype=torch.int32, device=dev)
+    d_c0 = torch.empty(P, dtype=torch.int32, device=dev)
+    ctx.match_pairs_dev(capi.NORM_HAMMING, d_desc, 2 * P, KPS * DESC_BYTES, KPS, None, DESC_BYTES,
+                        d_pairs, P, 0.5, d_m0, cap, d_c0)
+    ctx.synchronize()
+    n_in = d_c0.cpu().numpy().astype(np.int64)
+    d_m, d_c = torch.empty_like(d_m0), torch.empty_like(d_c0)
+    ctx.reserve(capi.Context.epipolar_filter_pairs_workspace(P, cap, 1000))
+
+    def step():
+        d_m.copy_(d_m0)      # the filter works in place: every step starts from the match lists
+        d_c.copy_(d_c0)
+        ctx.epipolar_filter_pairs_dev(d_kps, KPS * 28, 28, d_pairs, P, d_m, cap, d_c)
+
+    dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, ctx)
+    n_out = d_c.cpu().numpy().astype(np.int64)
+    out = {
+        "metric": "epipolar-filtered correspondences/sec (findFundamentalMat RANSAC per frame pair)",
+        "value": round(world * float(n_in.sum()) * args.steps / dt, 1), "unit": "correspondences/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"f1: epipolar filter of {P} frame pairs/rank/step, "
+                               f"{int(n_in.mean())} cross-checked matches per pair of {KPS} key "
+                               f"points, RANSAC 3 px / 0.99 / 1000"},
+        "ms_per_frame_pair": round(1e3 * dt / args.steps / P, 4),
+        "kernels": {k: kernel_line(prof, k) for k in sorted(prof)},
+        "check": {"matches_in": int(n_in.sum()), "matches_kept": int(n_out.sum())},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle
+
+        m = d_m0.cpu().numpy().view(capi.DMATCH_DTYPE).reshape(P, cap)
+        sets = []
+        for p in range(P):
+            mm = m[p][: n_in[p]]
+            sets.append((kps[2 * p, mm["queryIdx"], :2].copy(), kps[2 * p + 1, mm["trainIdx"], :2].copy()))
+        kept, iters, evals = 0, 0, 0.0
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            kept = 0
+            for a, b in sets:
+                _, _, mask, it = pyoracle.find_fundamental(a, b)
+                kept += int(mask.sum())
+                if reps == 0:
+                    iters += it
+                    evals += float(it) * len(a)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > 10.0 or (el > 3.0 and reps >= 3):
+                break
+        out["cpu_baseline"] = {"value": round(float(n_in.sum()) * reps / el, 1),
+                               "unit": "correspondences/s", "cores": 1, "kind": "port",
+                               "sample": f"the same {P} point sets x {reps} passes in {el:.1f} s, one "
+                                         f"thread, restatement not OpenCV; mean RANSAC iterations "
+                                         f"run {iters / P:.1f}",
+                               "ms_per_frame_pair": round(1e3 * el / reps / P, 4)}
+        out["check"]["cpu_matches_kept"] = kept
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
+        # the errors the sequential loop evaluates: iterations run x points (x models, not
+        # counted: at least one per iteration)
+        ms, cnt = prof.get("fm_score_kernel", (0.0, 0))
+        if cnt:
+            ach = evals * FM_ERROR_OPS / (ms / cnt * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "fm_score_kernel", "bound": "valu_f64",
+                               "achieved": round(ach, 4), "peak": F64_VALU_PEAK_TLANEOPS,
+                               "unit": "Tlane-op/s", "frac": round(ach / F64_VALU_PEAK_TLANEOPS, 5),
+                               "avg_launch_us": round(1e3 * ms / cnt, 2), "traffic": None,
+                               "algorithmic_per_launch": f"{evals:.4g} error evaluations (iterations "
+                                                         f"the sequential loop runs x points) x "
+                                                         f"{FM_ERROR_OPS} fp64 lane-ops"}
+    ctx.close()
+    return out
+
+
 def main():
     args = parse()
     rank, world, local = dist_setup(args.gpus)
-    run = {"framepair": run_framepair, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.workload]
+    run = {"framepair": run_framepair, "c3": run_c3, "c4": run_c4, "c5": run_c5, "f1": run_f1}[args.workload]
     out = run(args, rank, world, local)
     if rank == 0:
         print(json.dumps(out))
