@@ -6,15 +6,17 @@
 // OpenCV's loop is sequential: draw 7 correspondences, solve for up to three matrices, count
 // inliers, shrink the iteration budget when a better model appears.  Only two parts of it are
 // truly sequential, and both are tiny: the random draws (one generator, rejection of repeated
-// and collinear picks) and the "best so far / iterations left" bookkeeping.  So, per point set:
-//   1. one lane replays the draws and records every subset the loop could ever use;
-//   2. one lane per subset solves the 7-point problem;
-//   3. one wave per subset scores its models against all correspondences;
+// and collinear picks) and the "best so far / iterations left" bookkeeping.  The loop is
+// therefore run in rounds of iterations [0, 64), [64, 256), [256, 1024), ...; per round and
+// point set:
+//   1. one wave continues the draws and records the subsets of the round;
+//   2. one wave per subset solves the 7-point problem (one matrix element per lane);
+//   3. waves score the models against slices of the correspondences;
 //   4. one lane replays the bookkeeping over the recorded scores, in iteration order, and
-//      stops where OpenCV's loop would have stopped;
-//   5. the mask of the winning model is written.
-// Steps 2 and 3 evaluate subsets the sequential loop never reaches; they are cheap (a few
-// hundred microseconds for 32 point sets of 6000 correspondences) and independent.
+//      marks the point set done where OpenCV's loop would have stopped;
+// and at the end the mask of the winning model is written.  A point set that is done costs
+// the later rounds nothing but empty waves, so the work follows the iteration count the
+// sequential loop would have reached (tens, for the usual inlier ratios), not its maximum.
 //
 // The two-dimensional null space of the 7x9 system is taken by Gauss-Jordan elimination with
 // complete pivoting and Gram-Schmidt, not by OpenCV's SVD (whose basis of that plane depends
@@ -31,6 +33,21 @@ namespace {
 
 enum Regime { kNone = 0, kDirect = 1, kLmeds = 2, kRansac = 3 };
 
+// What the loop carries from one round to the next.
+struct FmState {
+    unsigned long long rng;
+    double min_median;
+    int32_t n_drawn;     // subsets recorded so far
+    int32_t reject_run;  // rejected attempts since the last accepted subset
+    int32_t exhausted;   // getSubset gave up: no further subsets exist
+    int32_t niters;      // the loop's current iteration budget
+    int32_t max_good;
+    int32_t best_it, best_m;
+    int32_t processed;   // iterations the bookkeeping has replayed
+    int32_t done;
+    int32_t pad;
+};
+
 struct FmArgs {
     const float2* pts1;
     const float2* pts2;
@@ -39,12 +56,14 @@ struct FmArgs {
     int count_uniform;
     int n_problems;
     int max_iters;
+    int lo, hi;             // iterations of this round
     double thresh, confidence;
+    FmState* state;     // [problem]
     int32_t* subsets;   // [problem][max_iters][7]
-    int32_t* n_drawn;   // [problem]
     double* models;     // [problem][max_iters][3][9]
     int32_t* n_models;  // [problem][max_iters]
-    float* scores;      // [problem][max_iters][3]: inlier count (RANSAC) or median error (LMedS)
+    int32_t* scores;    // [problem][max_iters][3]: inlier count (RANSAC) or the bits of the
+                        // float median error (LMedS)
     double* best;       // [problem][10]: matrix, inlier threshold
     double* F;          // [problem][9] or nullptr
     uint8_t* mask;      // [problem][stride]
@@ -60,72 +79,167 @@ __device__ __forceinline__ int regime_of(int count) {
     return count < 7 ? kNone : count == 7 ? kDirect : count < 15 ? kLmeds : kRansac;
 }
 
-// cv::RNG (multiply with carry)
-struct Rng {
-    unsigned long long state;
-    __device__ unsigned next() {
-        state = (unsigned long long)(unsigned)state * 4164903690ULL + (unsigned)(state >> 32);
-        return (unsigned)state;
-    }
-    __device__ int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
-};
-
 // haveCollinearPoints: is the last of the seven points on a line through two earlier ones
 __device__ bool have_collinear(const float2 (&m)[7]) {
     const int i = 6;
+    bool hit = false;
+#pragma unroll
     for (int j = 0; j < i; j++) {
         const double dx1 = m[j].x - m[i].x;
         const double dy1 = m[j].y - m[i].y;
+#pragma unroll
         for (int k = 0; k < j; k++) {
             const double dx2 = m[k].x - m[i].x;
             const double dy2 = m[k].y - m[i].y;
-            if (fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2)))
-                return true;
+            hit |= fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2));
         }
     }
-    return false;
+    return hit;
 }
 
-// Step 1: the subsets getSubset would hand to the loop, in order.
-__global__ void fm_subsets_kernel(FmArgs a) {
-    const int p = blockIdx.x;
-    if (threadIdx.x != 0) return;
+// RANSACUpdateNumIters
+__device__ int update_num_iters(double p, double ep, int model_points, int max_iters) {
+    p = p > 0 ? p : 0;
+    p = p < 1 ? p : 1;
+    ep = ep > 0 ? ep : 0;
+    ep = ep < 1 ? ep : 1;
+    double num = 1 - p > DBL_MIN ? 1 - p : DBL_MIN;
+    double denom = 1 - pow(1 - ep, (double)model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+constexpr int kRawPerBatch = 512;  // random numbers per batch of 64 attempts (7 each + repeats)
+
+// Step 1: the subsets getSubset would hand to the loop in this round, in order.  One wave per
+// point set.  cv::RNG (multiply with carry, seeded with ~0) is advanced by one lane; the
+// reduction of its outputs to indices, the rejection of repeated picks and the collinearity
+// test of 64 attempts run in parallel.  An attempt's place in the random stream depends on
+// the repeats in the attempts before it: the lanes assume none, measure their own, and
+// re-place themselves until nothing moves (at once when no pick repeats, the usual case).
+__global__ __launch_bounds__(64) void fm_subsets_kernel(FmArgs a) {
+    __shared__ unsigned long long raw[kRawPerBatch];
+    __shared__ int32_t pick_of[kRawPerBatch];
+    const int p = blockIdx.x, lane = threadIdx.x;
     const int count = problem_count(a, p);
     const int regime = regime_of(count);
-    int drawn = 0;
-    if (regime == kRansac || regime == kLmeds) {
+    FmState st;
+    if (a.lo == 0) {
+        st.rng = ~0ULL;
+        st.min_median = DBL_MAX;
+        st.n_drawn = 0;
+        st.reject_run = 0;
+        st.exhausted = 0;
+        st.niters = a.max_iters > 1 ? a.max_iters : 1;
+        if (regime == kLmeds) {
+            const int n = update_num_iters(a.confidence, 0.45, 7, a.max_iters);
+            st.niters = n > 3 ? n : 3;
+            if (st.niters > a.max_iters) st.niters = a.max_iters;
+        }
+        st.max_good = 0;
+        st.best_it = -1;
+        st.best_m = 0;
+        st.processed = 0;
+        st.done = !(regime == kRansac || regime == kLmeds);
+        st.pad = 0;
+    } else {
+        st = a.state[p];
+    }
+    if (!st.done) {
         const float2* m1 = a.pts1 + (size_t)p * a.stride;
         const float2* m2 = a.pts2 + (size_t)p * a.stride;
         int32_t* out = a.subsets + (size_t)p * a.max_iters * 7;
         const int max_attempts = regime == kRansac ? 10000 : 1000;
-        Rng rng{~0ULL};
-        for (; drawn < a.max_iters; ++drawn) {
+        const int target = min(min(a.hi, st.niters), a.max_iters);
+        while (st.n_drawn < target && !st.exhausted) {
+            if (lane == 0) {
+                unsigned long long x = st.rng;
+                for (int i = 0; i < kRawPerBatch; ++i) {
+                    x = (unsigned long long)(unsigned)x * 4164903690ULL + (unsigned)(x >> 32);
+                    raw[i] = x;
+                }
+            }
+            __syncthreads();
+            for (int i = lane; i < kRawPerBatch; i += 64) pick_of[i] = (int32_t)((unsigned)raw[i] % (unsigned)count);
+            __syncthreads();
             int idx[7];
-            float2 s1[7], s2[7];
-            int iters = 0;
-            bool complete = false;
-            for (; iters < max_attempts; iters++) {
+            int shift = 0, extra = 0;
+            bool complete = true;
+            for (;;) {
+                const int pos = 7 * lane + shift;
+                extra = 0;
+                complete = true;
+#pragma unroll
                 for (int i = 0; i < 7; ++i) {
-                    int pick;
+                    int pick = 0;
                     for (;;) {
-                        pick = rng.uniform(0, count);
+                        const int q = pos + i + extra;
+                        if (q >= kRawPerBatch) {
+                            complete = false;
+                            break;
+                        }
+                        pick = pick_of[q];
                         bool dup = false;
+#pragma unroll
                         for (int k = 0; k < i; ++k) dup |= idx[k] == pick;
                         if (!dup) break;
+                        ++extra;
                     }
                     idx[i] = pick;
-                    s1[i] = m1[pick];
-                    s2[i] = m2[pick];
                 }
-                complete = true;
-                if (have_collinear(s1) || have_collinear(s2)) continue;
+                if (!complete) extra = 0;
+                int incl = extra;  // inclusive prefix sum over the lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                const int placed = incl - extra;
+                const bool moved = placed != shift;
+                shift = placed;
+                if (!__any(moved)) break;
+            }
+            // attempts whose numbers all lie inside this batch: the lanes before the first
+            // incomplete one (a later lane's place depends on every earlier one)
+            const unsigned long long incomplete = __ballot(!complete);
+            const int n_att = incomplete ? __ffsll((long long)incomplete) - 1 : 64;
+            if (n_att == 0) {  // seven distinct picks not found in 512 draws: cannot happen with count >= 8
+                st.exhausted = 1;
                 break;
             }
-            if (!(complete && iters < max_attempts)) break;
-            for (int k = 0; k < 7; ++k) out[drawn * 7 + k] = idx[k];
+            bool ok = false;
+            if (lane < n_att) {
+                float2 s1[7], s2[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    s1[i] = m1[idx[i]];
+                    s2[i] = m2[idx[i]];
+                }
+                ok = !(have_collinear(s1) || have_collinear(s2));
+            }
+            const unsigned long long accepted = __ballot(ok);
+            const int first = accepted ? __ffsll((long long)accepted) - 1 : n_att;
+            if (st.reject_run + first >= max_attempts) {
+                st.exhausted = 1;  // max_attempts rejections in a row: getSubset fails, the loop ends
+            } else if (accepted) {
+                const int slot = st.n_drawn + __popcll(accepted & ((1ULL << lane) - 1ULL));
+                if (ok && slot < a.max_iters) {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) out[slot * 7 + k] = idx[k];
+                }
+                st.n_drawn = min(st.n_drawn + (int)__popcll(accepted), a.max_iters);
+                st.reject_run = n_att - 1 - (63 - __clzll((long long)accepted));
+            } else {
+                st.reject_run += n_att;
+            }
+            const int used = __shfl(7 * lane + shift + 7 + extra, n_att - 1);
+            st.rng = raw[used - 1];
+            __syncthreads();
         }
     }
-    a.n_drawn[p] = drawn;
+    if (lane == 0) a.state[p] = st;
 }
 
 // cv::solveCubic
@@ -201,82 +315,107 @@ __device__ int solve_cubic(const double (&c)[4], double (&roots)[3]) {
     return n;
 }
 
-// Orthonormal basis (f1, f2) of the null space of the 7x9 matrix a (destroyed).
-__device__ bool null_space_7x9(double* a, double* f1, double* f2) {
+// x of lane `src`, which every lane names alike.
+__device__ __forceinline__ double from_lane(double x, int src) {
+    src = __builtin_amdgcn_readfirstlane(src);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+}
+
+// Orthonormal basis (f1, f2) of the null space of a 7x9 matrix held one element per lane
+// (lane 9 r + c, lane 63 idle): Gauss-Jordan elimination with complete pivoting.  The pivot
+// is the first largest magnitude in row-major order, as a sequential scan would pick it.
+__device__ bool null_space_7x9(double a, int lane, double (&f1)[9], double (&f2)[9]) {
+    const bool valid = lane < 63;
+    const int r = lane / 9, c = lane - 9 * r;
+    unsigned used_cols = 0;
     int col_of[7];
-    bool used_col[9] = {false, false, false, false, false, false, false, false, false};
+#pragma unroll
     for (int k = 0; k < 7; ++k) {
-        int pr = -1, pc = -1;
-        double best = 0;
-        for (int r = k; r < 7; ++r)
-            for (int c = 0; c < 9; ++c) {
-                if (used_col[c]) continue;
-                const double v = fabs(a[r * 9 + c]);
-                if (v > best) {
-                    best = v;
-                    pr = r;
-                    pc = c;
-                }
+        const double mag = fabs(a);
+        double v = valid && r >= k && !((used_cols >> c) & 1u) && mag > 0 ? mag : -1.0;
+        int who = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(v, o);
+            const int ow = __shfl_xor(who, o);
+            if (ov > v || (ov == v && ow < who)) {
+                v = ov;
+                who = ow;
             }
-        if (pr < 0) return false;
-        if (pr != k)
-            for (int c = 0; c < 9; ++c) {
-                const double t = a[k * 9 + c];
-                a[k * 9 + c] = a[pr * 9 + c];
-                a[pr * 9 + c] = t;
-            }
-        used_col[pc] = true;
+        }
+        if (!(v > 0)) return false;
+        who = __builtin_amdgcn_readfirstlane(who);
+        const int pr = who / 9, pc = who - 9 * pr;
+        int src = lane;
+        if (valid && r == k) src = pr * 9 + c;
+        else if (valid && r == pr) src = k * 9 + c;
+        a = __shfl(a, src);
+        used_cols |= 1u << pc;
         col_of[k] = pc;
-        const double inv = 1.0 / a[k * 9 + pc];
-        for (int c = 0; c < 9; ++c) a[k * 9 + c] *= inv;
-        for (int r = 0; r < 7; ++r) {
-            if (r == k) continue;
-            const double m = a[r * 9 + pc];
-            if (m == 0) continue;
-            for (int c = 0; c < 9; ++c) a[r * 9 + c] -= m * a[k * 9 + c];
+        const double inv = 1.0 / from_lane(a, k * 9 + pc);
+        if (valid && r == k) a *= inv;
+        const double m = __shfl(a, valid ? r * 9 + pc : lane);
+        const double row_k = __shfl(a, k * 9 + c);
+        if (valid && r != k && m != 0) a -= m * row_k;
+    }
+    const unsigned free_mask = ~used_cols & 0x1ffu;
+    const int fc0 = __ffs((int)free_mask) - 1;
+    const int fc1 = __ffs((int)(free_mask & (free_mask - 1))) - 1;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        f1[j] = j == fc0 ? 1.0 : 0.0;
+        f2[j] = j == fc1 ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double t0 = -from_lane(a, k * 9 + fc0);
+        const double t1 = -from_lane(a, k * 9 + fc1);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            f1[j] = col_of[k] == j ? t0 : f1[j];
+            f2[j] = col_of[k] == j ? t1 : f2[j];
         }
     }
-    int free_cols[2], nf = 0;
-    for (int c = 0; c < 9; ++c)
-        if (!used_col[c]) free_cols[nf++] = c;
-    for (int v = 0; v < 2; ++v) {
-        double* f = v == 0 ? f1 : f2;
-        for (int c = 0; c < 9; ++c) f[c] = 0;
-        f[free_cols[v]] = 1.0;
-        for (int k = 0; k < 7; ++k) f[col_of[k]] = -a[k * 9 + free_cols[v]];
-    }
     double n2 = 0;
-    for (int c = 0; c < 9; ++c) n2 += f2[c] * f2[c];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) n2 += f2[j] * f2[j];
     double inv = 1.0 / sqrt(n2);
-    for (int c = 0; c < 9; ++c) f2[c] *= inv;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) f2[j] *= inv;
     double dot = 0;
-    for (int c = 0; c < 9; ++c) dot += f1[c] * f2[c];
-    for (int c = 0; c < 9; ++c) f1[c] -= dot * f2[c];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) dot += f1[j] * f2[j];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) f1[j] -= dot * f2[j];
     n2 = 0;
-    for (int c = 0; c < 9; ++c) n2 += f1[c] * f1[c];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) n2 += f1[j] * f1[j];
     inv = 1.0 / sqrt(n2);
-    for (int c = 0; c < 9; ++c) f1[c] *= inv;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) f1[j] *= inv;
     return true;
 }
 
-// run7Point
-__device__ int seven_point(const float2 (&m1)[7], const float2 (&m2)[7], double* fmatrix) {
-    double a[7 * 9], c[4], r[3] = {0, 0, 0};
+// run7Point, by one wave: lane 9 r + c holds the coefficient of matrix entry c in the
+// equation of correspondence r; `mine1`, `mine2` are that correspondence.  Everything after
+// the elimination is the same arithmetic in every lane.
+__device__ int seven_point(float2 mine1, float2 mine2, int lane, double* fmatrix) {
+    double c[4], r[3] = {0, 0, 0};
     double f1[9], f2[9];
-    for (int i = 0; i < 7; i++) {
-        const double x0 = m1[i].x, y0 = m1[i].y;
-        const double x1 = m2[i].x, y1 = m2[i].y;
-        a[i * 9 + 0] = x1 * x0;
-        a[i * 9 + 1] = x1 * y0;
-        a[i * 9 + 2] = x1;
-        a[i * 9 + 3] = y1 * x0;
-        a[i * 9 + 4] = y1 * y0;
-        a[i * 9 + 5] = y1;
-        a[i * 9 + 6] = x0;
-        a[i * 9 + 7] = y0;
-        a[i * 9 + 8] = 1;
+    {
+        const double x0 = mine1.x, y0 = mine1.y;
+        const double x1 = mine2.x, y1 = mine2.y;
+        const int col = lane % 9;
+        const double left = col < 3 ? x1 : col < 6 ? y1 : 1.0;
+        const int sub = col % 3;
+        const double right = sub == 0 ? x0 : sub == 1 ? y0 : 1.0;
+        // x1 x0, x1 y0, x1, y1 x0, y1 y0, y1, x0, y0, 1
+        const double coeff = col == 2 || col == 5 ? left : col >= 6 ? right : left * right;
+        if (!null_space_7x9(coeff, lane, f1, f2)) return 0;
     }
-    if (!null_space_7x9(a, f1, f2)) return 0;
+#pragma unroll
     for (int i = 0; i < 9; i++) f1[i] -= f2[i];
 
     double t0 = f2[4] * f2[8] - f2[5] * f2[7];
@@ -298,47 +437,54 @@ __device__ int seven_point(const float2 (&m1)[7], const float2 (&m2)[7], double*
 
     const int n = solve_cubic(c, r);
     if (n < 1 || n > 3) return n;
-    for (int k = 0; k < n; k++, fmatrix += 9) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (k >= n) break;
         double lambda = r[k], mu = 1.;
         const double s = f1[8] * r[k] + f2[8];
+        double last;
         if (fabs(s) > DBL_EPSILON) {
             mu = 1. / s;
             lambda *= mu;
-            fmatrix[8] = 1.;
+            last = 1.;
         } else
-            fmatrix[8] = 0.;
-        for (int i = 0; i < 8; i++) fmatrix[i] = f1[i] * lambda + f2[i] * mu;
+            last = 0.;
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) fmatrix[9 * k + i] = f1[i] * lambda + f2[i] * mu;
+            fmatrix[9 * k + 8] = last;
+        }
     }
     return n;
 }
 
-// Step 2: one lane per (problem, iteration).
-__global__ void fm_solve_kernel(FmArgs a) {
-    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+// Is iteration `it` of point set p one the loop can still reach?
+__device__ __forceinline__ bool iteration_live(const FmArgs& a, int p, int it, int regime) {
+    const FmState* st = a.state + p;
+    if (regime == kDirect) return it == 0;
+    return !st->done && it < st->niters && it < st->n_drawn;
+}
+
+// Step 2: one wave per (point set, iteration of the round).
+__global__ __launch_bounds__(256) void fm_solve_kernel(FmArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int it = a.lo + blockIdx.x * 4 + (threadIdx.x >> 6);
     const int p = blockIdx.y;
-    if (it >= a.max_iters) return;
+    if (it >= a.hi) return;
     const int count = problem_count(a, p);
     const int regime = regime_of(count);
-    int32_t* nm = a.n_models + (size_t)p * a.max_iters + it;
-    const bool direct = regime == kDirect && it == 0;
-    if (!direct && it >= a.n_drawn[p]) {
-        *nm = 0;
+    const size_t slot = (size_t)p * a.max_iters + it;
+    if (lane < 3) a.scores[slot * 3 + lane] = 0;
+    if (!iteration_live(a, p, it, regime)) {
+        if (lane == 0) a.n_models[slot] = 0;
         return;
     }
     const float2* m1 = a.pts1 + (size_t)p * a.stride;
     const float2* m2 = a.pts2 + (size_t)p * a.stride;
-    const int32_t* idx = a.subsets + ((size_t)p * a.max_iters + it) * 7;
-    float2 s1[7], s2[7];
-    for (int k = 0; k < 7; ++k) {
-        const int j = direct ? k : idx[k];
-        s1[k] = m1[j];
-        s2[k] = m2[j];
-    }
-    double F[27];
-    const int n = seven_point(s1, s2, F);
-    *nm = n;
-    double* out = a.models + ((size_t)p * a.max_iters + it) * 27;
-    for (int k = 0; k < n * 9 && k < 27; ++k) out[k] = F[k];
+    const int row = min(lane / 9, 6);
+    const int j = regime == kDirect ? row : a.subsets[slot * 7 + row];
+    const int n = seven_point(m1[j], m2[j], lane, a.models + slot * 27);
+    if (lane == 0) a.n_models[slot] = n;
 }
 
 // FMEstimatorCallback::computeError for one correspondence
@@ -358,37 +504,50 @@ __device__ __forceinline__ float epipolar_error(const double (&F)[9], float2 p1,
     return (float)(e1 > e2 ? e1 : e2);
 }
 
-// Step 3: one wave per (problem, iteration): inlier counts (RANSAC) or median error (LMedS)
-// of its models.
-__global__ __launch_bounds__(64) void fm_score_kernel(FmArgs a) {
-    const int it = blockIdx.x, p = blockIdx.y, lane = threadIdx.x;
+constexpr int kScoreSlice = 1024;  // correspondences per wave and pass of the scoring kernel
+
+// Step 3: inlier counts (RANSAC; one wave per slice of the correspondences, summed with
+// integer atomics) or median error (LMedS) of the models of each iteration of the round.
+__global__ __launch_bounds__(256) void fm_score_kernel(FmArgs a) {
+    const int it = a.lo + blockIdx.x, p = blockIdx.y, lane = threadIdx.x & 63;
+    const int wave = blockIdx.z * 4 + (threadIdx.x >> 6);
     const int count = problem_count(a, p);
     const int regime = regime_of(count);
-    const int n = a.n_models[(size_t)p * a.max_iters + it];
-    if (n <= 0 || n > 3 || (regime != kRansac && regime != kLmeds)) return;
+    if (regime != kRansac && regime != kLmeds) return;
+    if (!iteration_live(a, p, it, regime)) return;
+    const size_t slot = (size_t)p * a.max_iters + it;
+    const int n = a.n_models[slot];
+    if (n <= 0 || n > 3) return;
     const float2* m1 = a.pts1 + (size_t)p * a.stride;
     const float2* m2 = a.pts2 + (size_t)p * a.stride;
-    const double* src = a.models + ((size_t)p * a.max_iters + it) * 27;
-    float* out = a.scores + ((size_t)p * a.max_iters + it) * 3;
+    const double* src = a.models + slot * 27;
+    int32_t* out = a.scores + slot * 3;
     if (regime == kRansac) {
+        if (wave * kScoreSlice >= count) return;
         double F[3][9];
+#pragma unroll
         for (int m = 0; m < 3; ++m)
+#pragma unroll
             for (int k = 0; k < 9; ++k) F[m][k] = m < n ? src[m * 9 + k] : 0.0;
         const float t = (float)(a.thresh * a.thresh);
         int good[3] = {0, 0, 0};
-        for (int i = lane; i < count; i += 64) {
-            const float2 p1 = m1[i], p2 = m2[i];
+        for (int base = wave * kScoreSlice; base < count; base += gridDim.z * 4 * kScoreSlice) {
+            const int end = min(base + kScoreSlice, count);
+            for (int i = base + lane; i < end; i += 64) {
+                const float2 p1 = m1[i], p2 = m2[i];
 #pragma unroll
-            for (int m = 0; m < 3; ++m)
-                if (m < n) good[m] += epipolar_error(F[m], p1, p2) <= t;
+                for (int m = 0; m < 3; ++m)
+                    if (m < n) good[m] += epipolar_error(F[m], p1, p2) <= t;
+            }
         }
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             int v = good[m];
+#pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (lane == 0 && m < n) out[m] = (float)v;  // exact: counts are below 2^24
+            if (lane == 0 && m < n && v) atomicAdd(out + m, v);
         }
-    } else if (lane < n) {
+    } else if (wave == 0 && lane < n) {
         // std::nth_element(err, err + count / 2, err + count): count is at most 14
         double F[9];
         for (int k = 0; k < 9; ++k) F[k] = src[lane * 9 + k];
@@ -403,96 +562,89 @@ __global__ __launch_bounds__(64) void fm_score_kernel(FmArgs a) {
             }
             e[j + 1] = v;
         }
-        out[lane] = e[count / 2];
+        out[lane] = __float_as_int(e[count / 2]);
     }
 }
 
-// RANSACUpdateNumIters
-__device__ int update_num_iters(double p, double ep, int model_points, int max_iters) {
-    p = p > 0 ? p : 0;
-    p = p < 1 ? p : 1;
-    ep = ep > 0 ? ep : 0;
-    ep = ep < 1 ? ep : 1;
-    double num = 1 - p > DBL_MIN ? 1 - p : DBL_MIN;
-    double denom = 1 - pow(1 - ep, (double)model_points);
-    if (denom < DBL_MIN) return 0;
-    num = log(num);
-    denom = log(denom);
-    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
-}
-
-// Step 4: the loop's bookkeeping, replayed in iteration order.
+// Step 4: the loop's bookkeeping over the iterations of the round, replayed in order.
 __global__ void fm_select_kernel(FmArgs a) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.n_problems) return;
     const int count = problem_count(a, p);
     const int regime = regime_of(count);
+    FmState st = a.state[p];
+    if (st.done) return;
     const int32_t* nm = a.n_models + (size_t)p * a.max_iters;
-    const float* sc = a.scores + (size_t)p * a.max_iters * 3;
-    const double* models = a.models + (size_t)p * a.max_iters * 27;
-    double* best = a.best + (size_t)p * 10;
-    int best_it = -1, best_m = 0, found = 0;
-    double inlier_thresh = a.thresh;
-    if (regime == kDirect) {
-        found = nm[0] > 0;
-        best_it = found ? 0 : -1;
-    } else if (regime == kRansac) {
-        const int drawn = a.n_drawn[p];
-        int niters = a.max_iters > 1 ? a.max_iters : 1, max_good = 0;
-        for (int it = 0; it < niters && it < drawn; ++it) {
+    const int32_t* sc = a.scores + (size_t)p * a.max_iters * 3;
+    int it = st.processed;
+    if (regime == kRansac) {
+        for (; it < a.hi && it < st.niters && it < st.n_drawn; ++it) {
             const int n = nm[it];
             if (n <= 0) continue;
             for (int m = 0; m < n && m < 3; ++m) {
-                const int good = (int)sc[it * 3 + m];
-                if (good > (max_good > 6 ? max_good : 6)) {
-                    best_it = it;
-                    best_m = m;
-                    max_good = good;
-                    niters = update_num_iters(a.confidence, (double)(count - good) / count, 7, niters);
+                const int good = sc[it * 3 + m];
+                if (good > (st.max_good > 6 ? st.max_good : 6)) {
+                    st.best_it = it;
+                    st.best_m = m;
+                    st.max_good = good;
+                    st.niters = update_num_iters(a.confidence, (double)(count - good) / count, 7, st.niters);
                 }
             }
         }
-        found = max_good > 0;
-    } else if (regime == kLmeds) {
-        const int drawn = a.n_drawn[p];
-        int niters = update_num_iters(a.confidence, 0.45, 7, a.max_iters);
-        niters = niters > 3 ? niters : 3;
-        double min_median = DBL_MAX;
-        for (int it = 0; it < niters && it < drawn && it < a.max_iters; ++it) {
+    } else {
+        for (; it < a.hi && it < st.niters && it < st.n_drawn; ++it) {
             const int n = nm[it];
             if (n <= 0) continue;
             for (int m = 0; m < n && m < 3; ++m) {
-                const double median = sc[it * 3 + m];
-                if (median < min_median) {
-                    min_median = median;
-                    best_it = it;
-                    best_m = m;
+                const double median = __int_as_float(sc[it * 3 + m]);
+                if (median < st.min_median) {
+                    st.min_median = median;
+                    st.best_it = it;
+                    st.best_m = m;
                 }
             }
-        }
-        if (best_it >= 0) {
-            double sigma = 2.5 * 1.4826 * (1 + 5. / (count - 7)) * sqrt(min_median);
-            inlier_thresh = sigma > 0.001 ? sigma : 0.001;
-            found = 1;  // provisional: the mask kernel requires at least 7 inliers
         }
     }
-    for (int k = 0; k < 9; ++k) best[k] = best_it >= 0 ? models[(size_t)best_it * 27 + best_m * 9 + k] : 0.0;
-    best[9] = inlier_thresh;
-    a.found[p] = found;
-    if (a.F)
-        for (int k = 0; k < 9; ++k) a.F[(size_t)p * 9 + k] = best[k];
+    st.processed = it;
+    st.done = it >= st.niters || (st.exhausted && it >= st.n_drawn) || a.hi >= a.max_iters;
+    a.state[p] = st;
 }
 
-// Step 5: the mask of the chosen matrix (one workgroup per problem).
+// Step 5: the outcome and the mask of the chosen matrix (one workgroup per point set).
 __global__ __launch_bounds__(256) void fm_mask_kernel(FmArgs a) {
     __shared__ int total;
+    __shared__ int s_found;
+    __shared__ double s_best[10];
     const int p = blockIdx.x, tid = threadIdx.x;
     const int count = problem_count(a, p);
     const int regime = regime_of(count);
     uint8_t* mask = a.mask + (size_t)p * a.stride;
-    const int found = a.found[p];
-    if (tid == 0) total = 0;
+    if (tid == 0) {
+        const FmState st = a.state[p];
+        const double* models = a.models + (size_t)p * a.max_iters * 27;
+        int best_it = st.best_it, found = 0;
+        double inlier_thresh = a.thresh;
+        if (regime == kDirect) {
+            found = a.n_models[(size_t)p * a.max_iters] > 0;
+            best_it = found ? 0 : -1;
+        } else if (regime == kRansac) {
+            found = st.max_good > 0;
+        } else if (regime == kLmeds && best_it >= 0) {
+            const double sigma = 2.5 * 1.4826 * (1 + 5. / (count - 7)) * sqrt(st.min_median);
+            inlier_thresh = sigma > 0.001 ? sigma : 0.001;
+            found = 1;  // provisional: at least 7 inliers are required below
+        }
+        for (int k = 0; k < 9; ++k)
+            s_best[k] = best_it >= 0 ? models[(size_t)best_it * 27 + st.best_m * 9 + k] : 0.0;
+        s_best[9] = inlier_thresh;
+        s_found = found;
+        total = 0;
+        a.found[p] = found;
+        if (a.F)
+            for (int k = 0; k < 9; ++k) a.F[(size_t)p * 9 + k] = s_best[k];
+    }
     __syncthreads();
+    const int found = s_found;
     if (regime == kNone || (regime != kDirect && !found)) {
         // OpenCV leaves the caller's mask alone here; the reference hands in zeros
         for (int i = tid; i < count; i += blockDim.x) mask[i] = 0;
@@ -505,8 +657,8 @@ __global__ __launch_bounds__(256) void fm_mask_kernel(FmArgs a) {
     const float2* m1 = a.pts1 + (size_t)p * a.stride;
     const float2* m2 = a.pts2 + (size_t)p * a.stride;
     double F[9];
-    for (int k = 0; k < 9; ++k) F[k] = a.best[(size_t)p * 10 + k];
-    const double th = a.best[(size_t)p * 10 + 9];
+    for (int k = 0; k < 9; ++k) F[k] = s_best[k];
+    const double th = s_best[9];
     const float t = (float)(th * th);
     int good = 0;
     for (int i = tid; i < count; i += blockDim.x) {
@@ -575,11 +727,11 @@ __global__ __launch_bounds__(1024) void fm_compact_kernel(sfm_dmatch* __restrict
 }
 
 struct FmBuffers {
+    FmState* state;
     int32_t* subsets;
-    int32_t* n_drawn;
     double* models;
     int32_t* n_models;
-    float* scores;
+    int32_t* scores;
     double* best;
 };
 
@@ -588,39 +740,56 @@ FmBuffers carve_fm(Carver& c, int n_problems, int max_iters) {
     const size_t pi = (size_t)n_problems * max_iters;
     b.models = c.take<double>(pi * 27);
     b.best = c.take<double>((size_t)n_problems * 10);
+    b.state = c.take<FmState>((size_t)n_problems);
     b.subsets = c.take<int32_t>(pi * 7);
     b.n_models = c.take<int32_t>(pi);
-    b.scores = c.take<float>(pi * 3);
-    b.n_drawn = c.take<int32_t>((size_t)n_problems);
+    b.scores = c.take<int32_t>(pi * 3);
     return b;
 }
 
-// The five steps for the point sets described by `a`.
-int run_fm(sfm_ctx* ctx, const FmArgs& a) {
+void bind_fm(FmArgs& a, const FmBuffers& b) {
+    a.state = b.state;
+    a.subsets = b.subsets;
+    a.models = b.models;
+    a.n_models = b.n_models;
+    a.scores = b.scores;
+    a.best = b.best;
+}
+
+// The rounds for the point sets described by `args`, then the masks.
+int run_fm(sfm_ctx* ctx, const FmArgs& args) {
+    FmArgs a = args;
     const int n_problems = a.n_problems, max_iters = a.max_iters;
-    {
-        KernelTimer timer(ctx, KID_FM_SUBSETS);
-        hipLaunchKernelGGL(fm_subsets_kernel, dim3(n_problems), dim3(64), 0, ctx->stream, a);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
+    const size_t slices = (a.stride + kScoreSlice - 1) / kScoreSlice;
+    const unsigned score_z = (unsigned)std::min<size_t>((slices + 3) / 4, 1024);
+    for (int lo = 0, hi = std::min(64, max_iters);; lo = hi, hi = std::min(4 * hi, max_iters)) {
+        a.lo = lo;
+        a.hi = hi;
+        {
+            KernelTimer timer(ctx, KID_FM_SUBSETS);
+            hipLaunchKernelGGL(fm_subsets_kernel, dim3(n_problems), dim3(64), 0, ctx->stream, a);
+            SFM_HIP_CHECK(ctx, hipGetLastError());
+        }
+        {
+            KernelTimer timer(ctx, KID_FM_SOLVE);
+            hipLaunchKernelGGL(fm_solve_kernel, dim3((hi - lo + 3) / 4, n_problems), dim3(256), 0, ctx->stream, a);
+            SFM_HIP_CHECK(ctx, hipGetLastError());
+        }
+        {
+            KernelTimer timer(ctx, KID_FM_SCORE);
+            hipLaunchKernelGGL(fm_score_kernel, dim3(hi - lo, n_problems, score_z), dim3(256), 0, ctx->stream, a);
+            SFM_HIP_CHECK(ctx, hipGetLastError());
+        }
+        {
+            KernelTimer timer(ctx, KID_FM_SELECT);
+            hipLaunchKernelGGL(fm_select_kernel, dim3((n_problems + 63) / 64), dim3(64), 0, ctx->stream, a);
+            SFM_HIP_CHECK(ctx, hipGetLastError());
+        }
+        if (hi >= max_iters) break;
     }
-    {
-        KernelTimer timer(ctx, KID_FM_SOLVE);
-        hipLaunchKernelGGL(fm_solve_kernel, dim3((max_iters + 63) / 64, n_problems), dim3(64), 0,
-                           ctx->stream, a);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
-    }
-    {
-        KernelTimer timer(ctx, KID_FM_SCORE);
-        hipLaunchKernelGGL(fm_score_kernel, dim3(max_iters, n_problems), dim3(64), 0, ctx->stream, a);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
-    }
-    {
-        KernelTimer timer(ctx, KID_FM_SELECT);
-        hipLaunchKernelGGL(fm_select_kernel, dim3((n_problems + 63) / 64), dim3(64), 0, ctx->stream, a);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
-        hipLaunchKernelGGL(fm_mask_kernel, dim3(n_problems), dim3(256), 0, ctx->stream, a);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
-    }
+    KernelTimer timer(ctx, KID_FM_SELECT);
+    hipLaunchKernelGGL(fm_mask_kernel, dim3(n_problems), dim3(256), 0, ctx->stream, a);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
 }
 
@@ -668,12 +837,7 @@ int sfm_fundamental_dev(sfm_ctx* ctx, const float* d_pts1, const float* d_pts2, 
     a.max_iters = max_iters;
     a.thresh = thresh;
     a.confidence = confidence;
-    a.subsets = b.subsets;
-    a.n_drawn = b.n_drawn;
-    a.models = b.models;
-    a.n_models = b.n_models;
-    a.scores = b.scores;
-    a.best = b.best;
+    bind_fm(a, b);
     a.F = d_F;
     a.mask = d_mask;
     a.found = d_found;
@@ -765,12 +929,7 @@ int sfm_epipolar_filter_pairs_dev(sfm_ctx* ctx, const void* d_keypts, size_t fra
     a.max_iters = max_iters;
     a.thresh = thresh;
     a.confidence = confidence;
-    a.subsets = b.subsets;
-    a.n_drawn = b.n_drawn;
-    a.models = b.models;
-    a.n_models = b.n_models;
-    a.scores = b.scores;
-    a.best = b.best;
+    bind_fm(a, b);
     a.F = nullptr;
     a.mask = mask;
     a.found = found;
