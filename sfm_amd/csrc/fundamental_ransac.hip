@@ -113,40 +113,37 @@ __device__ int update_num_iters(double p, double ep, int model_points, int max_i
 
 constexpr int kRawPerBatch = 512;  // random numbers per batch of 64 attempts (7 each + repeats)
 
-// Step 1: the subsets getSubset would hand to the loop in this round, in order.  One wave per
-// point set.  cv::RNG (multiply with carry, seeded with ~0) is advanced by one lane; the
-// reduction of its outputs to indices, the rejection of repeated picks and the collinearity
-// test of 64 attempts run in parallel.  An attempt's place in the random stream depends on
-// the repeats in the attempts before it: the lanes assume none, measure their own, and
-// re-place themselves until nothing moves (at once when no pick repeats, the usual case).
-__global__ __launch_bounds__(64) void fm_subsets_kernel(FmArgs a) {
-    __shared__ unsigned long long raw[kRawPerBatch];
-    __shared__ int32_t pick_of[kRawPerBatch];
-    const int p = blockIdx.x, lane = threadIdx.x;
-    const int count = problem_count(a, p);
-    const int regime = regime_of(count);
+// The state of a point set before the first iteration.
+__device__ FmState initial_state(const FmArgs& a, int regime) {
     FmState st;
-    if (a.lo == 0) {
-        st.rng = ~0ULL;
-        st.min_median = DBL_MAX;
-        st.n_drawn = 0;
-        st.reject_run = 0;
-        st.exhausted = 0;
-        st.niters = a.max_iters > 1 ? a.max_iters : 1;
-        if (regime == kLmeds) {
-            const int n = update_num_iters(a.confidence, 0.45, 7, a.max_iters);
-            st.niters = n > 3 ? n : 3;
-            if (st.niters > a.max_iters) st.niters = a.max_iters;
-        }
-        st.max_good = 0;
-        st.best_it = -1;
-        st.best_m = 0;
-        st.processed = 0;
-        st.done = !(regime == kRansac || regime == kLmeds);
-        st.pad = 0;
-    } else {
-        st = a.state[p];
+    st.rng = ~0ULL;
+    st.min_median = DBL_MAX;
+    st.n_drawn = 0;
+    st.reject_run = 0;
+    st.exhausted = 0;
+    st.niters = a.max_iters > 1 ? a.max_iters : 1;
+    if (regime == kLmeds) {
+        const int n = update_num_iters(a.confidence, 0.45, 7, a.max_iters);
+        st.niters = n > 3 ? n : 3;
+        if (st.niters > a.max_iters) st.niters = a.max_iters;
     }
+    st.max_good = 0;
+    st.best_it = -1;
+    st.best_m = 0;
+    st.processed = 0;
+    st.done = !(regime == kRansac || regime == kLmeds);
+    st.pad = 0;
+    return st;
+}
+
+// Step 1: the subsets getSubset would hand to the loop up to iteration a.hi, in order.  By one
+// wave.  cv::RNG (multiply with carry, seeded with ~0) is advanced by one lane; the reduction
+// of its outputs to indices, the rejection of repeated picks and the collinearity test of 64
+// attempts run in parallel.  An attempt's place in the random stream depends on the repeats
+// in the attempts before it: the lanes assume none, measure their own, and re-place
+// themselves until nothing moves (at once when no pick repeats, the usual case).
+__device__ void draw_round(const FmArgs& a, int p, int count, int regime, FmState& st, int lane,
+                           unsigned long long* raw, int32_t* pick_of) {
     if (!st.done) {
         const float2* m1 = a.pts1 + (size_t)p * a.stride;
         const float2* m2 = a.pts2 + (size_t)p * a.stride;
@@ -239,6 +236,102 @@ __global__ __launch_bounds__(64) void fm_subsets_kernel(FmArgs a) {
             __syncthreads();
         }
     }
+}
+
+// Step 4: the loop's bookkeeping over the scored iterations [st.processed, hi), replayed in
+// order by one wave.  The lanes read 64 iterations at a time and find the ones that beat
+// everything before them (a running maximum of the inlier count, or minimum of the median);
+// only those change the state, and they are then applied one by one, so that the shrinking
+// iteration budget cuts the replay off exactly where it cuts the sequential loop off.
+__device__ void select_round(const FmArgs& a, int p, int count, int regime, FmState& st, int lane, int hi) {
+    if (st.done) return;
+    const int32_t* nm = a.n_models + (size_t)p * a.max_iters;
+    const int32_t* sc = a.scores + (size_t)p * a.max_iters * 3;
+    const int end = min(hi, st.n_drawn);
+    const bool ransac = regime == kRansac;
+    for (int base = st.processed; base < end && base < st.niters; base += 64) {
+        const int it = base + lane;
+        int n = 0;
+        int32_t s[3] = {0, 0, 0};
+        if (it < end) {
+            n = nm[it];
+            n = n < 0 ? 0 : (n > 3 ? 3 : n);
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                if (m < n) s[m] = sc[it * 3 + m];
+        }
+        // per-iteration figure of merit, larger is better
+        double merit = -DBL_MAX;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+            if (m < n) {
+                const double v = ransac ? (double)s[m] : -(double)__int_as_float(s[m]);
+                merit = v > merit ? v : merit;
+            }
+        double before = merit;  // best of the lanes before this one
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double v = __shfl_up(before, o);
+            if (lane >= o) before = v > before ? v : before;
+        }
+        before = __shfl_up(before, 1);
+        const double carried = ransac ? (double)(st.max_good > 6 ? st.max_good : 6) : -st.min_median;
+        if (lane == 0 || !(before > carried)) before = carried;
+        unsigned long long events = __ballot(n > 0 && merit > before);
+        bool cut = false;
+        while (events) {
+            const int l = __ffsll((long long)events) - 1;
+            events &= events - 1;
+            const int it_l = base + l;
+            if (it_l >= st.niters) {
+                cut = true;
+                break;
+            }
+            const int n_l = __builtin_amdgcn_readlane(n, l);
+            const int32_t s_l[3] = {__builtin_amdgcn_readlane(s[0], l), __builtin_amdgcn_readlane(s[1], l),
+                                    __builtin_amdgcn_readlane(s[2], l)};
+            for (int m = 0; m < n_l; ++m) {
+                if (ransac) {
+                    const int good = s_l[m];
+                    if (good > (st.max_good > 6 ? st.max_good : 6)) {
+                        st.best_it = it_l;
+                        st.best_m = m;
+                        st.max_good = good;
+                        st.niters = update_num_iters(a.confidence, (double)(count - good) / count, 7, st.niters);
+                    }
+                } else {
+                    const double median = __int_as_float(s_l[m]);
+                    if (median < st.min_median) {
+                        st.min_median = median;
+                        st.best_it = it_l;
+                        st.best_m = m;
+                    }
+                }
+            }
+        }
+        if (cut) break;
+    }
+    st.processed = min(end, st.niters);
+    st.done = st.processed >= st.niters || (st.exhausted && st.processed >= st.n_drawn) || hi >= a.max_iters;
+}
+
+// Between two rounds, one wave per point set: the bookkeeping of the round just scored
+// ([.., a.lo)), then the draws of the next one ([a.lo, a.hi)).
+__global__ __launch_bounds__(64) void fm_advance_kernel(FmArgs a) {
+    __shared__ unsigned long long raw[kRawPerBatch];
+    __shared__ int32_t pick_of[kRawPerBatch];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int count = problem_count(a, p);
+    const int regime = regime_of(count);
+    FmState st;
+    if (a.lo == 0) {
+        st = initial_state(a, regime);
+    } else {
+        st = a.state[p];
+        if (st.done) return;
+        select_round(a, p, count, regime, st, lane, a.lo);
+    }
+    draw_round(a, p, count, regime, st, lane, raw, pick_of);
     if (lane == 0) a.state[p] = st;
 }
 
@@ -504,6 +597,39 @@ __device__ __forceinline__ float epipolar_error(const double (&F)[9], float2 p1,
     return (float)(e1 > e2 ? e1 : e2);
 }
 
+// (float)epipolar_error(F, p1, p2) <= t, decided without the two divisions wherever the
+// outcome is not within rounding of the threshold.  `t_mid` is the midpoint between t and the
+// next float above it: errors below it convert to a float <= t.  With q the squared norm of
+// an epipolar line and d the point's residual, the error term is fl(fl(d d) fl(1 / q)), within
+// 2^-51 of d d / q; comparing d d with t_mid q at a margin of 2^-48 decides all but a sliver,
+// and there (and for any non-finite value) the reference expression itself is evaluated.
+__device__ __forceinline__ bool epipolar_inlier(const double (&F)[9], double x1, double y1, double x2, double y2,
+                                                float2 p1, float2 p2, double t_mid, float t) {
+    const double a2 = F[0] * x1 + F[1] * y1 + F[2];
+    const double b2 = F[3] * x1 + F[4] * y1 + F[5];
+    const double c2 = F[6] * x1 + F[7] * y1 + F[8];
+    const double q2 = a2 * a2 + b2 * b2;
+    const double d2 = x2 * a2 + y2 * b2 + c2;
+    const double a1 = F[0] * x2 + F[3] * y2 + F[6];
+    const double b1 = F[1] * x2 + F[4] * y2 + F[7];
+    const double c1 = F[2] * x2 + F[5] * y2 + F[8];
+    const double q1 = a1 * a1 + b1 * b1;
+    const double d1 = x1 * a1 + y1 * b1 + c1;
+    const double dd1 = d1 * d1, dd2 = d2 * d2;
+    const double lim1 = t_mid * q1, lim2 = t_mid * q2;
+    const double below = 1.0 - 0x1p-48, above = 1.0 + 0x1p-48;
+    const bool in1 = dd1 < lim1 * below, in2 = dd2 < lim2 * below;
+    const bool out1 = dd1 > lim1 * above, out2 = dd2 > lim2 * above;
+    if ((in1 || out1) && (in2 || out2)) return in1 && in2;
+    return epipolar_error(F, p1, p2) <= t;
+}
+
+// The midpoint between t and the next float above it.
+__device__ __forceinline__ double float_upper_midpoint(float t) {
+    const float next = __int_as_float(__float_as_int(t) + 1);  // t is positive and finite
+    return 0.5 * ((double)t + (double)next);
+}
+
 constexpr int kScoreSlice = 1024;  // correspondences per wave and pass of the scoring kernel
 
 // Step 3: inlier counts (RANSAC; one wave per slice of the correspondences, summed with
@@ -530,14 +656,16 @@ __global__ __launch_bounds__(256) void fm_score_kernel(FmArgs a) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) F[m][k] = m < n ? src[m * 9 + k] : 0.0;
         const float t = (float)(a.thresh * a.thresh);
+        const double t_mid = float_upper_midpoint(t);
         int good[3] = {0, 0, 0};
         for (int base = wave * kScoreSlice; base < count; base += gridDim.z * 4 * kScoreSlice) {
             const int end = min(base + kScoreSlice, count);
             for (int i = base + lane; i < end; i += 64) {
                 const float2 p1 = m1[i], p2 = m2[i];
+                const double x1 = p1.x, y1 = p1.y, x2 = p2.x, y2 = p2.y;
 #pragma unroll
                 for (int m = 0; m < 3; ++m)
-                    if (m < n) good[m] += epipolar_error(F[m], p1, p2) <= t;
+                    if (m < n) good[m] += epipolar_inlier(F[m], x1, y1, x2, y2, p1, p2, t_mid, t);
             }
         }
 #pragma unroll
@@ -566,113 +694,6 @@ __global__ __launch_bounds__(256) void fm_score_kernel(FmArgs a) {
     }
 }
 
-// Step 4: the loop's bookkeeping over the iterations of the round, replayed in order.
-__global__ void fm_select_kernel(FmArgs a) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.n_problems) return;
-    const int count = problem_count(a, p);
-    const int regime = regime_of(count);
-    FmState st = a.state[p];
-    if (st.done) return;
-    const int32_t* nm = a.n_models + (size_t)p * a.max_iters;
-    const int32_t* sc = a.scores + (size_t)p * a.max_iters * 3;
-    int it = st.processed;
-    if (regime == kRansac) {
-        for (; it < a.hi && it < st.niters && it < st.n_drawn; ++it) {
-            const int n = nm[it];
-            if (n <= 0) continue;
-            for (int m = 0; m < n && m < 3; ++m) {
-                const int good = sc[it * 3 + m];
-                if (good > (st.max_good > 6 ? st.max_good : 6)) {
-                    st.best_it = it;
-                    st.best_m = m;
-                    st.max_good = good;
-                    st.niters = update_num_iters(a.confidence, (double)(count - good) / count, 7, st.niters);
-                }
-            }
-        }
-    } else {
-        for (; it < a.hi && it < st.niters && it < st.n_drawn; ++it) {
-            const int n = nm[it];
-            if (n <= 0) continue;
-            for (int m = 0; m < n && m < 3; ++m) {
-                const double median = __int_as_float(sc[it * 3 + m]);
-                if (median < st.min_median) {
-                    st.min_median = median;
-                    st.best_it = it;
-                    st.best_m = m;
-                }
-            }
-        }
-    }
-    st.processed = it;
-    st.done = it >= st.niters || (st.exhausted && it >= st.n_drawn) || a.hi >= a.max_iters;
-    a.state[p] = st;
-}
-
-// Step 5: the outcome and the mask of the chosen matrix (one workgroup per point set).
-__global__ __launch_bounds__(256) void fm_mask_kernel(FmArgs a) {
-    __shared__ int total;
-    __shared__ int s_found;
-    __shared__ double s_best[10];
-    const int p = blockIdx.x, tid = threadIdx.x;
-    const int count = problem_count(a, p);
-    const int regime = regime_of(count);
-    uint8_t* mask = a.mask + (size_t)p * a.stride;
-    if (tid == 0) {
-        const FmState st = a.state[p];
-        const double* models = a.models + (size_t)p * a.max_iters * 27;
-        int best_it = st.best_it, found = 0;
-        double inlier_thresh = a.thresh;
-        if (regime == kDirect) {
-            found = a.n_models[(size_t)p * a.max_iters] > 0;
-            best_it = found ? 0 : -1;
-        } else if (regime == kRansac) {
-            found = st.max_good > 0;
-        } else if (regime == kLmeds && best_it >= 0) {
-            const double sigma = 2.5 * 1.4826 * (1 + 5. / (count - 7)) * sqrt(st.min_median);
-            inlier_thresh = sigma > 0.001 ? sigma : 0.001;
-            found = 1;  // provisional: at least 7 inliers are required below
-        }
-        for (int k = 0; k < 9; ++k)
-            s_best[k] = best_it >= 0 ? models[(size_t)best_it * 27 + st.best_m * 9 + k] : 0.0;
-        s_best[9] = inlier_thresh;
-        s_found = found;
-        total = 0;
-        a.found[p] = found;
-        if (a.F)
-            for (int k = 0; k < 9; ++k) a.F[(size_t)p * 9 + k] = s_best[k];
-    }
-    __syncthreads();
-    const int found = s_found;
-    if (regime == kNone || (regime != kDirect && !found)) {
-        // OpenCV leaves the caller's mask alone here; the reference hands in zeros
-        for (int i = tid; i < count; i += blockDim.x) mask[i] = 0;
-        return;
-    }
-    if (regime == kDirect) {
-        for (int i = tid; i < count; i += blockDim.x) mask[i] = 1;
-        return;
-    }
-    const float2* m1 = a.pts1 + (size_t)p * a.stride;
-    const float2* m2 = a.pts2 + (size_t)p * a.stride;
-    double F[9];
-    for (int k = 0; k < 9; ++k) F[k] = s_best[k];
-    const double th = s_best[9];
-    const float t = (float)(th * th);
-    int good = 0;
-    for (int i = tid; i < count; i += blockDim.x) {
-        const int f = epipolar_error(F, m1[i], m2[i]) <= t;
-        mask[i] = (uint8_t)f;
-        good += f;
-    }
-    if (regime == kLmeds) {
-        atomicAdd(&total, good);
-        __syncthreads();
-        if (tid == 0) a.found[p] = total >= 7;
-    }
-}
-
 // Aligned point lists of every pair: pts[p][i] = key point of matches[p][i]
 // (Source Files/feature_processing.cpp:164-165).
 __global__ void fm_gather_kernel(const sfm_dmatch* __restrict__ matches, const int32_t* __restrict__ counts,
@@ -690,24 +711,66 @@ __global__ void fm_gather_kernel(const sfm_dmatch* __restrict__ matches, const i
     }
 }
 
-// Keeps the matches whose mask entry is set, in order (Source Files/
-// feature_processing.cpp:193-204 with useEpipolarFilter == true, then :223).  One workgroup
-// per pair; in place: an element is only ever moved to a lower index, and a whole chunk is
-// read before any of it is written.
-__global__ __launch_bounds__(1024) void fm_compact_kernel(sfm_dmatch* __restrict__ matches,
-                                                          int32_t* __restrict__ counts, int cap,
-                                                          const uint8_t* __restrict__ mask) {
+// Step 5, one workgroup per point set: the bookkeeping of the last round, the outcome, the
+// mask of the chosen matrix and, when `matches` is given, the matches whose mask entry is set,
+// kept in order (Source Files/feature_processing.cpp:193-204 with useEpipolarFilter == true,
+// then :223).  The compaction is in place: an element only ever moves to a lower index, and
+// a whole chunk is read before any of it is written.
+__global__ __launch_bounds__(1024) void fm_finish_kernel(FmArgs a, sfm_dmatch* __restrict__ matches,
+                                                         int32_t* match_counts) {
     __shared__ int wave_count[16];
+    __shared__ int s_found;
+    __shared__ double s_best[10];
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = min(counts[p], cap);
-    sfm_dmatch* mine = matches + (size_t)p * cap;
-    const uint8_t* keep = mask + (size_t)p * cap;
+    const int count = problem_count(a, p);
+    const int regime = regime_of(count);
+    uint8_t* mask = a.mask + (size_t)p * a.stride;
+    if (wave == 0) {
+        FmState st = a.state[p];
+        select_round(a, p, count, regime, st, lane, a.hi);
+        if (lane == 0) {
+            const double* models = a.models + (size_t)p * a.max_iters * 27;
+            int best_it = st.best_it, found = 0;
+            double inlier_thresh = a.thresh;
+            if (regime == kDirect) {
+                found = a.n_models[(size_t)p * a.max_iters] > 0;
+                best_it = found ? 0 : -1;
+            } else if (regime == kRansac) {
+                found = st.max_good > 0;
+            } else if (regime == kLmeds && best_it >= 0) {
+                const double sigma = 2.5 * 1.4826 * (1 + 5. / (count - 7)) * sqrt(st.min_median);
+                inlier_thresh = sigma > 0.001 ? sigma : 0.001;
+                found = 1;  // provisional: at least 7 inliers are required below
+            }
+            for (int k = 0; k < 9; ++k)
+                s_best[k] = best_it >= 0 ? models[(size_t)best_it * 27 + st.best_m * 9 + k] : 0.0;
+            s_best[9] = inlier_thresh;
+            s_found = found;
+            if (a.F)
+                for (int k = 0; k < 9; ++k) a.F[(size_t)p * 9 + k] = s_best[k];
+        }
+    }
+    __syncthreads();
+    const int found = s_found;
+    // OpenCV leaves the caller's mask alone when nothing is found; the reference hands in zeros
+    const int fixed = regime == kNone || (regime != kDirect && !found) ? 0 : regime == kDirect ? 1 : -1;
+    const float2* m1 = a.pts1 + (size_t)p * a.stride;
+    const float2* m2 = a.pts2 + (size_t)p * a.stride;
+    double F[9];
+    for (int k = 0; k < 9; ++k) F[k] = s_best[k];
+    const double th = s_best[9];
+    const float t = (float)(th * th);
+    sfm_dmatch* mine = matches ? matches + (size_t)p * a.stride : nullptr;
     int running = 0;
-    for (int i0 = 0; i0 < n; i0 += 1024) {
+    for (int i0 = 0; i0 < count; i0 += 1024) {
         const int i = i0 + tid;
-        const bool ok = i < n && keep[i] != 0;
+        bool ok = false;
+        if (i < count) {
+            ok = fixed >= 0 ? fixed != 0 : epipolar_error(F, m1[i], m2[i]) <= t;
+            mask[i] = (uint8_t)ok;
+        }
         sfm_dmatch m{};
-        if (ok) m = mine[i];
+        if (ok && mine) m = mine[i];
         const unsigned long long ballot = __ballot(ok);
         const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
         if (lane == 0) wave_count[wave] = __popcll(ballot);
@@ -719,11 +782,14 @@ __global__ __launch_bounds__(1024) void fm_compact_kernel(sfm_dmatch* __restrict
             offset += w < wave ? c : 0;
             total += c;
         }
-        if (ok) mine[running + offset + prefix] = m;
+        if (ok && mine) mine[running + offset + prefix] = m;
         running += total;
         __syncthreads();
     }
-    if (tid == 0) counts[p] = running;
+    if (tid == 0) {
+        a.found[p] = regime == kLmeds && found ? running >= 7 : found;
+        if (match_counts) match_counts[p] = running;
+    }
 }
 
 struct FmBuffers {
@@ -756,8 +822,9 @@ void bind_fm(FmArgs& a, const FmBuffers& b) {
     a.best = b.best;
 }
 
-// The rounds for the point sets described by `args`, then the masks.
-int run_fm(sfm_ctx* ctx, const FmArgs& args) {
+// The rounds for the point sets described by `args`, then the masks (and, for match lists
+// whose capacity is the point stride, their compaction).
+int run_fm(sfm_ctx* ctx, const FmArgs& args, sfm_dmatch* matches = nullptr, int32_t* match_counts = nullptr) {
     FmArgs a = args;
     const int n_problems = a.n_problems, max_iters = a.max_iters;
     const size_t slices = (a.stride + kScoreSlice - 1) / kScoreSlice;
@@ -767,7 +834,7 @@ int run_fm(sfm_ctx* ctx, const FmArgs& args) {
         a.hi = hi;
         {
             KernelTimer timer(ctx, KID_FM_SUBSETS);
-            hipLaunchKernelGGL(fm_subsets_kernel, dim3(n_problems), dim3(64), 0, ctx->stream, a);
+            hipLaunchKernelGGL(fm_advance_kernel, dim3(n_problems), dim3(64), 0, ctx->stream, a);
             SFM_HIP_CHECK(ctx, hipGetLastError());
         }
         {
@@ -780,15 +847,10 @@ int run_fm(sfm_ctx* ctx, const FmArgs& args) {
             hipLaunchKernelGGL(fm_score_kernel, dim3(hi - lo, n_problems, score_z), dim3(256), 0, ctx->stream, a);
             SFM_HIP_CHECK(ctx, hipGetLastError());
         }
-        {
-            KernelTimer timer(ctx, KID_FM_SELECT);
-            hipLaunchKernelGGL(fm_select_kernel, dim3((n_problems + 63) / 64), dim3(64), 0, ctx->stream, a);
-            SFM_HIP_CHECK(ctx, hipGetLastError());
-        }
         if (hi >= max_iters) break;
     }
     KernelTimer timer(ctx, KID_FM_SELECT);
-    hipLaunchKernelGGL(fm_mask_kernel, dim3(n_problems), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(fm_finish_kernel, dim3(n_problems), dim3(1024), 0, ctx->stream, a, matches, match_counts);
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
 }
@@ -931,16 +993,9 @@ int sfm_epipolar_filter_pairs_dev(sfm_ctx* ctx, const void* d_keypts, size_t fra
     a.confidence = confidence;
     bind_fm(a, b);
     a.F = nullptr;
-    a.mask = mask;
+    a.mask = d_mask ? d_mask : mask;
     a.found = found;
-    SFM_RETURN_IF(run_fm(ctx, a));
-    if (d_mask)
-        SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_mask, mask, (size_t)n_pairs * cap, hipMemcpyDeviceToDevice,
-                                          ctx->stream));
-    KernelTimer timer(ctx, KID_FM_SELECT);
-    hipLaunchKernelGGL(fm_compact_kernel, dim3(n_pairs), dim3(1024), 0, ctx->stream, d_matches,
-                       d_match_counts, cap, mask);
-    SFM_HIP_CHECK(ctx, hipGetLastError());
+    SFM_RETURN_IF(run_fm(ctx, a, d_matches, d_match_counts));
     return SFM_OK;
 }
 
