@@ -493,8 +493,9 @@ __device__ bool null_space_7x9(double a, int lane, double (&f1)[9], double (&f2)
 
 // run7Point, by one wave: lane 9 r + c holds the coefficient of matrix entry c in the
 // equation of correspondence r; `mine1`, `mine2` are that correspondence.  Everything after
-// the elimination is the same arithmetic in every lane.
-__device__ int seven_point(float2 mine1, float2 mine2, int lane, double* fmatrix) {
+// the elimination is the same arithmetic in every lane; lane 0 writes the matrices found to
+// `fmatrix` and to `copy`.
+__device__ int seven_point(float2 mine1, float2 mine2, int lane, double* fmatrix, double* copy) {
     double c[4], r[3] = {0, 0, 0};
     double f1[9], f2[9];
     {
@@ -544,45 +545,15 @@ __device__ int seven_point(float2 mine1, float2 mine2, int lane, double* fmatrix
             last = 0.;
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) fmatrix[9 * k + i] = f1[i] * lambda + f2[i] * mu;
-            fmatrix[9 * k + 8] = last;
+            for (int i = 0; i < 8; i++) copy[9 * k + i] = fmatrix[9 * k + i] = f1[i] * lambda + f2[i] * mu;
+            copy[9 * k + 8] = fmatrix[9 * k + 8] = last;
         }
     }
     return n;
 }
 
-// Is iteration `it` of point set p one the loop can still reach?
-__device__ __forceinline__ bool iteration_live(const FmArgs& a, int p, int it, int regime) {
-    const FmState* st = a.state + p;
-    if (regime == kDirect) return it == 0;
-    return !st->done && it < st->niters && it < st->n_drawn;
-}
-
-// Step 2: one wave per (point set, iteration of the round).
-__global__ __launch_bounds__(256) void fm_solve_kernel(FmArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int it = a.lo + blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int p = blockIdx.y;
-    if (it >= a.hi) return;
-    const int count = problem_count(a, p);
-    const int regime = regime_of(count);
-    const size_t slot = (size_t)p * a.max_iters + it;
-    if (lane < 3) a.scores[slot * 3 + lane] = 0;
-    if (!iteration_live(a, p, it, regime)) {
-        if (lane == 0) a.n_models[slot] = 0;
-        return;
-    }
-    const float2* m1 = a.pts1 + (size_t)p * a.stride;
-    const float2* m2 = a.pts2 + (size_t)p * a.stride;
-    const int row = min(lane / 9, 6);
-    const int j = regime == kDirect ? row : a.subsets[slot * 7 + row];
-    const int n = seven_point(m1[j], m2[j], lane, a.models + slot * 27);
-    if (lane == 0) a.n_models[slot] = n;
-}
-
 // FMEstimatorCallback::computeError for one correspondence
-__device__ __forceinline__ float epipolar_error(const double (&F)[9], float2 p1, float2 p2) {
-    const double x1 = p1.x, y1 = p1.y, x2 = p2.x, y2 = p2.y;
+__device__ __forceinline__ float epipolar_error(const double (&F)[9], double x1, double y1, double x2, double y2) {
     double a = F[0] * x1 + F[1] * y1 + F[2];
     double b = F[3] * x1 + F[4] * y1 + F[5];
     double c = F[6] * x1 + F[7] * y1 + F[8];
@@ -597,14 +568,75 @@ __device__ __forceinline__ float epipolar_error(const double (&F)[9], float2 p1,
     return (float)(e1 > e2 ? e1 : e2);
 }
 
+__device__ __forceinline__ float epipolar_error(const double (&F)[9], float2 p1, float2 p2) {
+    return epipolar_error(F, (double)p1.x, (double)p1.y, (double)p2.x, (double)p2.y);
+}
+
+// End of the iterations of the round [a.lo, a.hi) that the loop of point set p can still
+// reach (a.lo when there are none).
+__device__ __forceinline__ int live_end(const FmArgs& a, int p, int regime) {
+    if (regime == kDirect) return a.lo == 0 ? 1 : a.lo;
+    const FmState* st = a.state + p;
+    if ((regime != kRansac && regime != kLmeds) || st->done) return a.lo;
+    return max(a.lo, min(a.hi, min(st->niters, st->n_drawn)));
+}
+
+// Step 2: one wave per (point set, live iteration of the round); for point sets of 8 to 14
+// correspondences also their scores (step 3), the median error of each matrix.
+__global__ __launch_bounds__(256) void fm_solve_kernel(FmArgs a) {
+    __shared__ float s_err[4][3][14];
+    __shared__ double s_models[4][27];
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.y;
+    const int count = problem_count(a, p);
+    const int regime = regime_of(count);
+    const int end = live_end(a, p, regime);
+    const float2* m1 = a.pts1 + (size_t)p * a.stride;
+    const float2* m2 = a.pts2 + (size_t)p * a.stride;
+    const int row = min(lane / 9, 6);
+    for (int it = a.lo + blockIdx.x * 4 + (threadIdx.x >> 6); it < end; it += gridDim.x * 4) {
+        const size_t slot = (size_t)p * a.max_iters + it;
+        if (lane < 3) a.scores[slot * 3 + lane] = 0;
+        const int j = regime == kDirect ? row : a.subsets[slot * 7 + row];
+        double* copy = s_models[threadIdx.x >> 6];
+        const int n = seven_point(m1[j], m2[j], lane, a.models + slot * 27, copy);
+        if (lane == 0) a.n_models[slot] = n;
+        if (regime == kLmeds) {
+            __threadfence_block();  // lane 0's matrices in LDS, for the lanes of this wave
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (regime == kLmeds && lane < n) {
+            // least median of squares, one lane per matrix: std::nth_element(err, err +
+            // count / 2, err + count) of at most 14 errors
+            double mine[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) mine[k] = copy[9 * lane + k];
+            float* e = s_err[threadIdx.x >> 6][lane];  // rare regime: kept out of the registers
+#pragma unroll 1
+            for (int i = 0; i < count; ++i) {
+                const float v = epipolar_error(mine, m1[i], m2[i]);
+                int q = i - 1;
+#pragma unroll 1
+                while (q >= 0 && e[q] > v) {
+                    e[q + 1] = e[q];
+                    --q;
+                }
+                e[q + 1] = v;
+            }
+            a.scores[slot * 3 + lane] = __float_as_int(e[count / 2]);
+        }
+    }
+}
+
 // (float)epipolar_error(F, p1, p2) <= t, decided without the two divisions wherever the
-// outcome is not within rounding of the threshold.  `t_mid` is the midpoint between t and the
-// next float above it: errors below it convert to a float <= t.  With q the squared norm of
-// an epipolar line and d the point's residual, the error term is fl(fl(d d) fl(1 / q)), within
-// 2^-51 of d d / q; comparing d d with t_mid q at a margin of 2^-48 decides all but a sliver,
-// and there (and for any non-finite value) the reference expression itself is evaluated.
+// outcome is not within rounding of the threshold.  Errors below the midpoint between t and the
+// next float above it convert to a float <= t.  With q the squared norm of an epipolar line
+// and d the point's residual, the error term is fl(fl(d d) fl(1 / q)), within 2^-51 of d d / q;
+// comparing d d with q times the midpoint, at a margin of 2^-48 either way (t_lo, t_hi),
+// decides all but a sliver, and there (and for any non-finite value) the reference expression
+// itself is evaluated.
 __device__ __forceinline__ bool epipolar_inlier(const double (&F)[9], double x1, double y1, double x2, double y2,
-                                                float2 p1, float2 p2, double t_mid, float t) {
+                                                double t_lo, double t_hi, float t) {
     const double a2 = F[0] * x1 + F[1] * y1 + F[2];
     const double b2 = F[3] * x1 + F[4] * y1 + F[5];
     const double c2 = F[6] * x1 + F[7] * y1 + F[8];
@@ -616,12 +648,12 @@ __device__ __forceinline__ bool epipolar_inlier(const double (&F)[9], double x1,
     const double q1 = a1 * a1 + b1 * b1;
     const double d1 = x1 * a1 + y1 * b1 + c1;
     const double dd1 = d1 * d1, dd2 = d2 * d2;
-    const double lim1 = t_mid * q1, lim2 = t_mid * q2;
-    const double below = 1.0 - 0x1p-48, above = 1.0 + 0x1p-48;
-    const bool in1 = dd1 < lim1 * below, in2 = dd2 < lim2 * below;
-    const bool out1 = dd1 > lim1 * above, out2 = dd2 > lim2 * above;
-    if ((in1 || out1) && (in2 || out2)) return in1 && in2;
-    return epipolar_error(F, p1, p2) <= t;
+    const bool in1 = dd1 < t_lo * q1, in2 = dd2 < t_lo * q2;
+    const bool out1 = dd1 > t_hi * q1, out2 = dd2 > t_hi * q2;
+    const bool decided = (in1 | out1) & (in2 | out2);
+    bool inlier = in1 & in2;
+    if (__builtin_expect(!decided, 0)) inlier = epipolar_error(F, x1, y1, x2, y2) <= t;
+    return inlier;
 }
 
 // The midpoint between t and the next float above it.
@@ -632,31 +664,33 @@ __device__ __forceinline__ double float_upper_midpoint(float t) {
 
 constexpr int kScoreSlice = 1024;  // correspondences per wave and pass of the scoring kernel
 
-// Step 3: inlier counts (RANSAC; one wave per slice of the correspondences, summed with
-// integer atomics) or median error (LMedS) of the models of each iteration of the round.
+// Step 3 (RANSAC): inlier counts of the models of each live iteration of the round; one wave
+// per slice of the correspondences, summed with integer atomics.  Bound by the rate of fp64
+// instructions: about 48 per correspondence and model, none of them fused (the results have
+// to match a CPU evaluation that rounds after every operation).
 __global__ __launch_bounds__(256) void fm_score_kernel(FmArgs a) {
-    const int it = a.lo + blockIdx.x, p = blockIdx.y, lane = threadIdx.x & 63;
+    const int p = blockIdx.y, lane = threadIdx.x & 63;
     const int wave = blockIdx.z * 4 + (threadIdx.x >> 6);
     const int count = problem_count(a, p);
     const int regime = regime_of(count);
-    if (regime != kRansac && regime != kLmeds) return;
-    if (!iteration_live(a, p, it, regime)) return;
-    const size_t slot = (size_t)p * a.max_iters + it;
-    const int n = a.n_models[slot];
-    if (n <= 0 || n > 3) return;
+    if (regime != kRansac || wave * kScoreSlice >= count) return;
+    const int it_end = live_end(a, p, regime);
     const float2* m1 = a.pts1 + (size_t)p * a.stride;
     const float2* m2 = a.pts2 + (size_t)p * a.stride;
-    const double* src = a.models + slot * 27;
-    int32_t* out = a.scores + slot * 3;
-    if (regime == kRansac) {
-        if (wave * kScoreSlice >= count) return;
+    const float t = (float)(a.thresh * a.thresh);
+    const double t_lo = float_upper_midpoint(t) * (1.0 - 0x1p-48);
+    const double t_hi = float_upper_midpoint(t) * (1.0 + 0x1p-48);
+    for (int it = a.lo + blockIdx.x; it < it_end; it += gridDim.x) {
+        const size_t slot = (size_t)p * a.max_iters + it;
+        const int n = a.n_models[slot];
+        if (n <= 0 || n > 3) continue;
+        const double* src = a.models + slot * 27;
+        int32_t* out = a.scores + slot * 3;
         double F[3][9];
 #pragma unroll
         for (int m = 0; m < 3; ++m)
 #pragma unroll
             for (int k = 0; k < 9; ++k) F[m][k] = m < n ? src[m * 9 + k] : 0.0;
-        const float t = (float)(a.thresh * a.thresh);
-        const double t_mid = float_upper_midpoint(t);
         int good[3] = {0, 0, 0};
         for (int base = wave * kScoreSlice; base < count; base += gridDim.z * 4 * kScoreSlice) {
             const int end = min(base + kScoreSlice, count);
@@ -665,7 +699,7 @@ __global__ __launch_bounds__(256) void fm_score_kernel(FmArgs a) {
                 const double x1 = p1.x, y1 = p1.y, x2 = p2.x, y2 = p2.y;
 #pragma unroll
                 for (int m = 0; m < 3; ++m)
-                    if (m < n) good[m] += epipolar_inlier(F[m], x1, y1, x2, y2, p1, p2, t_mid, t);
+                    if (m < n) good[m] += epipolar_inlier(F[m], x1, y1, x2, y2, t_lo, t_hi, t);
             }
         }
 #pragma unroll
@@ -675,22 +709,6 @@ __global__ __launch_bounds__(256) void fm_score_kernel(FmArgs a) {
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
             if (lane == 0 && m < n && v) atomicAdd(out + m, v);
         }
-    } else if (wave == 0 && lane < n) {
-        // std::nth_element(err, err + count / 2, err + count): count is at most 14
-        double F[9];
-        for (int k = 0; k < 9; ++k) F[k] = src[lane * 9 + k];
-        float e[14];
-        for (int i = 0; i < 14; ++i) e[i] = i < count ? epipolar_error(F, m1[i], m2[i]) : FLT_MAX;
-        for (int i = 1; i < 14; ++i) {
-            const float v = e[i];
-            int j = i - 1;
-            while (j >= 0 && e[j] > v) {
-                e[j + 1] = e[j];
-                --j;
-            }
-            e[j + 1] = v;
-        }
-        out[lane] = __float_as_int(e[count / 2]);
     }
 }
 
@@ -839,12 +857,12 @@ int run_fm(sfm_ctx* ctx, const FmArgs& args, sfm_dmatch* matches = nullptr, int3
         }
         {
             KernelTimer timer(ctx, KID_FM_SOLVE);
-            hipLaunchKernelGGL(fm_solve_kernel, dim3((hi - lo + 3) / 4, n_problems), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(fm_solve_kernel, dim3(std::min((hi - lo + 3) / 4, 64), n_problems), dim3(256), 0, ctx->stream, a);
             SFM_HIP_CHECK(ctx, hipGetLastError());
         }
         {
             KernelTimer timer(ctx, KID_FM_SCORE);
-            hipLaunchKernelGGL(fm_score_kernel, dim3(hi - lo, n_problems, score_z), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(fm_score_kernel, dim3(std::min(hi - lo, 128), n_problems, score_z), dim3(256), 0, ctx->stream, a);
             SFM_HIP_CHECK(ctx, hipGetLastError());
         }
         if (hi >= max_iters) break;
