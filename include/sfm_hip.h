@@ -253,6 +253,32 @@ int sfm_epipolar_filter_pairs_dev(sfm_ctx* ctx, const void* d_keypts, size_t fra
                                   double confidence, int max_iters, uint8_t* d_mask);
 size_t sfm_epipolar_filter_pairs_workspace(int n_pairs, int cap, int max_iters);
 
+/* ---- corner detection (producer of the tracker's input) --------------------------------- */
+
+/* cv::goodFeaturesToTrack(imGray, _corners, maxCorners, qualityLevel, minDistance) of
+ * FeatureDetector::generateFlowFeatures, Source Files/feature_processing.cpp:87-99
+ * (Shi-Tomasi: no mask, blockSize 3, Sobel aperture 3, useHarrisDetector false).
+ * img: w x h 8-bit gray, `stride` bytes between rows, host memory.  corners: room for `cap`
+ * (x, y) float pairs; *count receives the number found, strongest first.  max_corners == 0
+ * means no limit (OpenCV's convention); quality > 0, min_distance >= 0 as OpenCV asserts.
+ * The image must be at least 3 x 3. */
+int sfm_good_features(sfm_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, int max_corners,
+                      double quality, double min_distance, float* corners, int cap, int* count);
+
+/* The same on a device-resident image, enqueued on the context's stream without a host
+ * round trip.  d_info receives three int32: corners written, local maxima above the
+ * threshold, and 1 if those exceeded the candidate capacity (then the corners are those of the
+ * candidates that fitted and the call should be repeated with a larger max_candidates;
+ * 0 selects w*h/4 + 1024, enough unless the image has plateaus of equal corner strength). */
+int sfm_good_features_dev(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size_t stride, int max_corners,
+                          double quality, double min_distance, int max_candidates, float* d_corners,
+                          int cap, int32_t* d_info);
+size_t sfm_good_features_workspace(int w, int h, int max_candidates);
+
+/* cv::cornerMinEigenVal(image, eig, 3, 3), the first stage of the above: d_eig is [h][w]
+ * float, dense. */
+int sfm_min_eigen_val_dev(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size_t stride, float* d_eig);
+
 #ifdef __cplusplus
 }
 #endif

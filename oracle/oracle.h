@@ -13,7 +13,8 @@
  * modules/features2d/src/matchers.cpp, modules/video/src/lkpyramid.cpp,
  * modules/imgproc/src/pyramids.cpp, modules/calib3d/src/triangulate.cpp,
  * modules/calib3d/src/calibration.cpp, modules/calib3d/src/fundam.cpp,
- * modules/calib3d/src/ptsetreg.cpp) and are anchored on the reference's
+ * modules/calib3d/src/ptsetreg.cpp, modules/imgproc/src/featureselect.cpp,
+ * modules/imgproc/src/corner.cpp) and are anchored on the reference's
  * own call sites, cited per function as "Source Files/<file>:<line>".
  * They are checked against independently written NumPy vectors under
  * tests/golden/, not against OpenCV itself.
@@ -144,6 +145,19 @@ int orc_fm_subsets(const float* m1, const float* m2, int count, int max_iters, i
                    int32_t* idx);
 /* RANSACUpdateNumIters */
 int orc_ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
+
+/* ---- corner detection ----------------------------------------------------- */
+
+/* cv::cornerMinEigenVal(image, eig, 3, 3) as goodFeaturesToTrack calls it
+ * (Source Files/feature_processing.cpp:93): eig is [h][w] float. */
+void orc_min_eigen_val(const uint8_t* img, int w, int h, size_t stride, float* eig);
+
+/* cv::goodFeaturesToTrack(imGray, corners, maxCorners, qualityLevel, minDistance),
+ * Source Files/feature_processing.cpp:93.  corners: room for max_out (x, y) pairs; returns
+ * the number written; max_corners <= 0 means no limit; n_candidates (optional) receives the
+ * number of thresholded local maxima. */
+int orc_good_features(const uint8_t* img, int w, int h, size_t stride, int max_corners, double quality,
+                      double min_distance, float* corners, int max_out, int* n_candidates);
 
 #ifdef __cplusplus
 }

@@ -222,3 +222,28 @@ def svd4_null(A):
     v = np.zeros(4)
     lib().orc_svd4_null(_p(A), _p(w), _p(v))
     return w, v
+
+
+def min_eigen_val(img):
+    """cv::cornerMinEigenVal(img, 3, 3): float32 [h, w]."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    eig = np.zeros((h, w), np.float32)
+    lib().orc_min_eigen_val(_p(img), C.c_int(w), C.c_int(h), C.c_size_t(w), _p(eig))
+    return eig
+
+
+def good_features(img, max_corners, quality, min_distance, return_candidates=False):
+    """cv::goodFeaturesToTrack(img, maxCorners, qualityLevel, minDistance): float32 [n, 2]."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    cap = w * h if max_corners <= 0 else max_corners
+    out = np.zeros((max(cap, 1), 2), np.float32)
+    ncand = C.c_int(0)
+    f = lib().orc_good_features
+    f.restype = C.c_int
+    n = f(_p(img), C.c_int(w), C.c_int(h), C.c_size_t(w), C.c_int(max_corners), C.c_double(quality),
+          C.c_double(min_distance), _p(out), C.c_int(cap), C.byref(ncand))
+    if return_candidates:
+        return out[:n].copy(), ncand.value
+    return out[:n].copy()

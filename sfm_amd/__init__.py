@@ -9,7 +9,7 @@ There is no CPU fallback: without the library or without a GPU every compute
 call raises.
 """
 from . import capi  # noqa: F401
-from .feature_processing import DescriptorMatcher, OptFlow  # noqa: F401
+from .feature_processing import DescriptorMatcher, FeatureDetector, OptFlow  # noqa: F401
 from .reconstruction import CameraParameters, Reconstruction  # noqa: F401
 
-__all__ = ["capi", "DescriptorMatcher", "OptFlow", "Reconstruction", "CameraParameters"]
+__all__ = ["capi", "DescriptorMatcher", "FeatureDetector", "OptFlow", "Reconstruction", "CameraParameters"]

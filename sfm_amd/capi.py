@@ -36,6 +36,8 @@ EXPORTS = [
     "sfm_triangulate", "sfm_triangulate_dev", "sfm_triangulate_matches_dev",
     "sfm_fundamental", "sfm_fundamental_dev", "sfm_fundamental_workspace",
     "sfm_epipolar_filter_pairs_dev", "sfm_epipolar_filter_pairs_workspace",
+    "sfm_good_features", "sfm_good_features_dev", "sfm_good_features_workspace",
+    "sfm_min_eigen_val_dev",
 ]
 
 
@@ -62,7 +64,7 @@ def lib():
         l.sfm_ctx_destroy.restype = None
         l.sfm_ctx_destroy.argtypes = [C.c_void_p]
         for name in ("sfm_match_pairs_workspace", "sfm_pyrlk_workspace", "sfm_fundamental_workspace",
-                     "sfm_epipolar_filter_pairs_workspace"):
+                     "sfm_epipolar_filter_pairs_workspace", "sfm_good_features_workspace"):
             if hasattr(l, name):
                 getattr(l, name).restype = C.c_size_t
         _lib = l
@@ -323,6 +325,37 @@ class Context:
     def epipolar_filter_pairs_workspace(n_pairs, cap, max_iters=1000):
         return int(lib().sfm_epipolar_filter_pairs_workspace(C.c_int(n_pairs), C.c_int(cap),
                                                              C.c_int(max_iters)))
+
+    def good_features(self, img, max_corners, quality, min_distance):
+        """cv::goodFeaturesToTrack(img, maxCorners, qualityLevel, minDistance): float32 [n, 2],
+        strongest first (host image in, host corners out)."""
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1:
+            raise ValueError("image must be a 2-D uint8 array with contiguous rows")
+        h, w = img.shape
+        cap = int(max_corners) if max_corners > 0 else w * h
+        out = np.zeros((max(cap, 1), 2), np.float32)
+        count = C.c_int(0)
+        self.check(lib().sfm_good_features(self._h, _ptr(img), C.c_int(w), C.c_int(h),
+                                           C.c_size_t(img.strides[0]), C.c_int(max_corners),
+                                           C.c_double(quality), C.c_double(min_distance), _ptr(out),
+                                           C.c_int(cap), C.byref(count)))
+        return out[:count.value].copy()
+
+    def good_features_dev(self, d_img, w, h, stride, max_corners, quality, min_distance, d_corners, cap,
+                          d_info, max_candidates=0):
+        self.check(lib().sfm_good_features_dev(
+            self._h, _ptr(d_img), C.c_int(w), C.c_int(h), C.c_size_t(stride), C.c_int(max_corners),
+            C.c_double(quality), C.c_double(min_distance), C.c_int(max_candidates), _ptr(d_corners),
+            C.c_int(cap), _ptr(d_info)))
+
+    @staticmethod
+    def good_features_workspace(w, h, max_candidates=0):
+        return int(lib().sfm_good_features_workspace(C.c_int(w), C.c_int(h), C.c_int(max_candidates)))
+
+    def min_eigen_val_dev(self, d_img, w, h, stride, d_eig):
+        self.check(lib().sfm_min_eigen_val_dev(self._h, _ptr(d_img), C.c_int(w), C.c_int(h),
+                                               C.c_size_t(stride), _ptr(d_eig)))
 
     @staticmethod
     def fundamental_workspace(n_problems, max_iters):

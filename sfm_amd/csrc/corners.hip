@@ -1,0 +1,507 @@
+// Shi-Tomasi corners: cv::goodFeaturesToTrack(imGray, corners, maxCorners, qualityLevel,
+// minDistance) as FeatureDetector::generateFlowFeatures calls it
+// (Source Files/feature_processing.cpp:87-99): no mask, 3x3 block, 3x3 Sobel, no Harris.
+//
+//   1. corner_eig_kernel     Sobel -> products -> 3x3 box sum -> smaller eigenvalue, one pass
+//                            over the image through LDS tiles; image maximum by atomics.
+//   2. corner_pick_kernel    threshold at max * qualityLevel, 3x3 local maxima of the interior,
+//                            appended as sortable keys (value bits << 32 | y * w + x).
+//   3. radix sort, descending: by value, ties by address, both descending, as OpenCV's
+//      std::sort with greaterThanPtr orders its pointers.
+//   4. corner_rank_kernel    position -> rank image.
+//   5. corner_select_kernel  the greedy minimum-distance pass.  Sequentially, a candidate is
+//                            kept unless an already kept one in the 3x3 grid cells around it is
+//                            closer than minDistance.  Here every undecided candidate looks at
+//                            the stronger candidates in its window each round: one of them kept
+//                            -> dropped; all of them dropped -> kept; otherwise it waits.  A
+//                            decision is only ever taken on final information, so the fixed
+//                            point is the sequential answer whatever the schedule; rounds that
+//                            find nothing left exit at once, and a single-wave sequential pass
+//                            settles whatever a fixed number of rounds left open.
+//   6. corner_emit_kernel    the kept candidates, in rank order, up to maxCorners.
+//
+// All float arithmetic is unfused and ordered as in the CPU restatement: Sobel smoothing
+// (s0 + s2) * k1 + s1 * k0 with the scale 1 / (4 * 3 * 255) folded into the taps, box sums
+// ((l + m) + r) per row then ((top + mid) + bottom), eig = (a + c) - sqrt((a - c)^2 + b^2).
+#include <cmath>
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "sfm_internal.h"
+
+namespace sfm {
+
+namespace {
+
+constexpr int kTileW = 64, kTileH = 16;  // outputs per workgroup of 256 threads
+constexpr int kSelectRounds = 24;
+
+struct CornerArgs {
+    const uint8_t* img;
+    int w, h;
+    size_t stride;
+    float* eig;             // [h][w]
+    unsigned* max_bits;     // ordered bits of the image maximum
+    unsigned long long* keys;     // [cap] appended candidates
+    unsigned long long* sorted;   // [cap]
+    int32_t* rank;          // [h][w], -1 where no candidate
+    int32_t* state;         // [cap] 0 undecided, 1 kept, 2 dropped
+    int32_t* counters;      // [0] candidates found, [1] overflow, [2 + r] undecided after round r
+    int cap;
+    double quality, min_distance;
+    int max_corners;
+};
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * n - 2 - i : i;
+    return min(max(i, 0), n - 1);
+}
+
+// Monotone map of float order onto unsigned order.
+__device__ __forceinline__ unsigned ordered_bits(float v) {
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ __launch_bounds__(256) void corner_eig_kernel(CornerArgs a) {
+    __shared__ uint8_t s_img[kTileH + 4][kTileW + 4];
+    __shared__ float2 s_d[kTileH + 2][kTileW + 2];
+    __shared__ unsigned s_max;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    if (tid == 0) s_max = 0;
+    for (int i = tid; i < (kTileH + 4) * (kTileW + 4); i += 256) {
+        const int ty = i / (kTileW + 4), tx = i - ty * (kTileW + 4);
+        const int gx = reflect101(x0 - 2 + tx, a.w), gy = reflect101(y0 - 2 + ty, a.h);
+        s_img[ty][tx] = a.img[(size_t)gy * a.stride + gx];
+    }
+    __syncthreads();
+    const double scale = 1.0 / (4.0 * 3.0 * 255.0);
+    const float k0 = (float)(2.0 * scale), k1 = (float)(1.0 * scale);
+    // derivatives on the tile and a ring of one; outside the image they are the derivatives
+    // AT the reflected position (the box filter reflects the products, not the image)
+    for (int i = tid; i < (kTileH + 2) * (kTileW + 2); i += 256) {
+        const int ty = i / (kTileW + 2), tx = i - ty * (kTileW + 2);
+        const int X = x0 - 1 + tx, Y = y0 - 1 + ty;
+        float2 d = make_float2(0.f, 0.f);
+        if (X <= a.w && Y <= a.h) {
+            const int cx = reflect101(X, a.w) - (x0 - 2), cy = reflect101(Y, a.h) - (y0 - 2);
+            const uint8_t* r0 = &s_img[cy - 1][cx];
+            const uint8_t* r1 = &s_img[cy][cx];
+            const uint8_t* r2 = &s_img[cy + 1][cx];
+            const float d0 = (float)((int)r0[1] - (int)r0[-1]);
+            const float d1 = (float)((int)r1[1] - (int)r1[-1]);
+            const float d2 = (float)((int)r2[1] - (int)r2[-1]);
+            d.x = (d0 + d2) * k1 + d1 * k0;
+            const float s0 = (float)((int)r0[-1] + (int)r0[1]) * k1 + (float)r0[0] * k0;
+            const float s2 = (float)((int)r2[-1] + (int)r2[1]) * k1 + (float)r2[0] * k0;
+            d.y = s2 - s0;
+        }
+        s_d[ty][tx] = d;
+    }
+    __syncthreads();
+    unsigned best = 0;
+    const int px = tid & (kTileW - 1);
+#pragma unroll
+    for (int k = 0; k < kTileH / 4; ++k) {
+        const int py = (tid >> 6) + 4 * k;
+        const int x = x0 + px, y = y0 + py;
+        if (x >= a.w || y >= a.h) continue;
+        float rows[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float p[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float2 g = s_d[py + j][px + i];
+                p[0][i] = g.x * g.x;
+                p[1][i] = g.x * g.y;
+                p[2][i] = g.y * g.y;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rows[c][j] = (p[c][0] + p[c][1]) + p[c][2];
+        }
+        const float cxx = (rows[0][0] + rows[0][1]) + rows[0][2];
+        const float cxy = (rows[1][0] + rows[1][1]) + rows[1][2];
+        const float cyy = (rows[2][0] + rows[2][1]) + rows[2][2];
+        const float aa = cxx * 0.5f, bb = cxy, cc = cyy * 0.5f;
+        const float e = (aa + cc) - sqrtf((aa - cc) * (aa - cc) + bb * bb);
+        a.eig[(size_t)y * a.w + x] = e;
+        best = max(best, ordered_bits(e));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
+    if ((tid & 63) == 0) atomicMax(&s_max, best);
+    __syncthreads();
+    if (tid == 0 && s_max) atomicMax(a.max_bits, s_max);
+}
+
+__global__ __launch_bounds__(256) void corner_pick_kernel(CornerArgs a) {
+    const int x = 1 + blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = 1 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    // minMaxLoc's double maximum times the double quality level, then threshold()'s float
+    const float thresh = (float)((double)from_ordered_bits(*a.max_bits) * a.quality);
+    bool pick = false;
+    float v = 0.f;
+    if (x < a.w - 1 && y < a.h - 1) {
+        const float* e = a.eig + (size_t)y * a.w + x;
+        v = e[0] > thresh ? e[0] : 0.f;  // THRESH_TOZERO
+        if (v != 0.f) {
+            float m = v;  // 3x3 dilation of the thresholded image
+#pragma unroll
+            for (int j = -1; j <= 1; ++j)
+#pragma unroll
+                for (int i = -1; i <= 1; ++i) {
+                    const float u = e[j * a.w + i];
+                    m = fmaxf(m, u > thresh ? u : 0.f);
+                }
+            pick = v == m;
+        }
+    }
+    const unsigned long long ballot = __ballot(pick);
+    if (!ballot) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(a.counters, (int)__popcll(ballot));
+    base = __shfl(base, 0);
+    if (pick) {
+        const int slot = base + (int)__popcll(ballot & ((1ULL << lane) - 1ULL));
+        if (slot < a.cap)
+            a.keys[slot] = ((unsigned long long)ordered_bits(v) << 32) | (unsigned)(y * a.w + x);
+        else
+            a.counters[1] = 1;
+    }
+}
+
+__device__ __forceinline__ int candidate_count(const CornerArgs& a) { return min(a.counters[0], a.cap); }
+
+// States are read and written past the per-CU cache: a wave may then see decisions other
+// waves took earlier in the same launch.  A stale read can only show "undecided", which
+// delays a decision and never changes it.
+__device__ __forceinline__ int load_state(const CornerArgs& a, int i) {
+    return __hip_atomic_load(a.state + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_state(const CornerArgs& a, int i, int s) {
+    __hip_atomic_store(a.state + i, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void corner_rank_kernel(CornerArgs a) {
+    const int n = candidate_count(a);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        a.rank[(unsigned)(a.sorted[i] & 0xffffffffu)] = i;
+}
+
+// Decision for candidate i from the states of the stronger candidates around it:
+// 1 kept, 2 dropped, 0 cannot be told yet.  By one wave.
+__device__ int decide(const CornerArgs& a, int i, int lane, int cell, int reach) {
+    const unsigned pos = (unsigned)(a.sorted[i] & 0xffffffffu);
+    const int y = (int)(pos / (unsigned)a.w), x = (int)(pos - (unsigned)y * a.w);
+    const int xc = x / cell, yc = y / cell;
+    const int side = 2 * reach + 1;
+    const double md2 = a.min_distance * a.min_distance;
+    bool dropped = false, waiting = false;
+    for (int t = lane; t < side * side; t += 64) {
+        const int dy = t / side - reach, dx = t - (dy + reach) * side - reach;
+        const int nx = x + dx, ny = y + dy;
+        if (nx < 0 || ny < 0 || nx >= a.w || ny >= a.h) continue;
+        const int j = a.rank[(size_t)ny * a.w + nx];
+        if (j < 0 || j >= i) continue;
+        // the accepted corner is only met if its cell is one of the 3x3 around this one
+        const int cxd = nx / cell - xc, cyd = ny / cell - yc;
+        if (cxd < -1 || cxd > 1 || cyd < -1 || cyd > 1) continue;
+        const float fx = (float)x - (float)nx, fy = (float)y - (float)ny;
+        if (!((double)(fx * fx + fy * fy) < md2)) continue;
+        const int s = load_state(a, j);
+        dropped |= s == 1;
+        waiting |= s == 0;
+    }
+    if (__any(dropped)) return 2;
+    if (__any(waiting)) return 0;
+    return 1;
+}
+
+__global__ __launch_bounds__(256) void corner_select_kernel(CornerArgs a, int round) {
+    const int n = candidate_count(a);
+    if (round > 0 && a.counters[2 + round - 1] == 0) return;  // settled in an earlier round
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const int cell = max((int)rint(a.min_distance), 1);
+    const int reach = max((int)ceil(a.min_distance) - 1, 0);
+    int open = 0;
+    for (int i = wave; i < n; i += n_waves) {
+        if (load_state(a, i) != 0) continue;
+        const int s = a.min_distance >= 1 ? decide(a, i, lane, cell, reach) : 1;
+        if (s == 0)
+            ++open;
+        else if (lane == 0)
+            store_state(a, i, s);
+    }
+    if (lane == 0 && open) atomicAdd(a.counters + 2 + round, open);
+}
+
+// Whatever the rounds left open, in order, by one wave.
+__global__ __launch_bounds__(64) void corner_settle_kernel(CornerArgs a) {
+    if (a.counters[2 + kSelectRounds - 1] == 0) return;
+    const int n = candidate_count(a);
+    const int lane = threadIdx.x;
+    const int cell = max((int)rint(a.min_distance), 1);
+    const int reach = max((int)ceil(a.min_distance) - 1, 0);
+    for (int i = 0; i < n; ++i) {
+        if (load_state(a, i) != 0) continue;
+        const int s = decide(a, i, lane, cell, reach);  // every stronger candidate is settled
+        if (lane == 0) store_state(a, i, s);
+        __threadfence();
+    }
+}
+
+// out[0] = corners written, out[1] = candidates, out[2] = 1 if candidates were lost to the
+// capacity.
+__global__ __launch_bounds__(1024) void corner_emit_kernel(CornerArgs a, float2* __restrict__ corners, int cap_out,
+                                                           int32_t* __restrict__ out) {
+    __shared__ int wave_count[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = candidate_count(a);
+    int limit = cap_out;
+    if (a.max_corners > 0) limit = min(limit, a.max_corners);
+    int running = 0;
+    for (int i0 = 0; i0 < n && running < limit; i0 += 1024) {
+        const int i = i0 + tid;
+        const bool ok = i < n && a.state[i] == 1;
+        const unsigned long long ballot = __ballot(ok);
+        const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_count[wave] = __popcll(ballot);
+        __syncthreads();
+        int offset = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = wave_count[w];
+            offset += w < wave ? c : 0;
+            total += c;
+        }
+        const int slot = running + offset + prefix;
+        if (ok && slot < limit) {
+            const unsigned pos = (unsigned)(a.sorted[i] & 0xffffffffu);
+            const int y = (int)(pos / (unsigned)a.w), x = (int)(pos - (unsigned)y * a.w);
+            corners[slot] = make_float2((float)x, (float)y);
+        }
+        running += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[0] = min(running, limit);
+        out[1] = a.counters[0];
+        out[2] = a.counters[1];
+    }
+}
+
+int default_capacity(int w, int h) {
+    // strict 3x3 local maxima fill at most a quarter of the pixels; plateaus of equal values
+    // can exceed that, and are reported as overflow
+    const size_t px = (size_t)w * h;
+    return (int)std::min<size_t>(px, px / 4 + 1024);
+}
+
+size_t sort_temp_bytes(int cap) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_keys_desc(nullptr, bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                        (size_t)cap, 0, 64, nullptr);
+    return bytes;
+}
+
+struct CornerBuffers {
+    float* eig;
+    int32_t* rank;
+    unsigned long long *keys, *sorted;
+    int32_t* state;
+    unsigned* max_bits;
+    int32_t* counters;
+    int32_t* out;
+    void* sort_temp;
+    size_t sort_bytes;
+};
+
+CornerBuffers carve_corners(Carver& c, int w, int h, int cap) {
+    CornerBuffers b;
+    const size_t px = (size_t)w * h;
+    b.eig = c.take<float>(px);
+    b.rank = c.take<int32_t>(px);
+    b.keys = c.take<unsigned long long>((size_t)cap);
+    b.sorted = c.take<unsigned long long>((size_t)cap);
+    b.state = c.take<int32_t>((size_t)cap);
+    // one block to clear: maximum, counters, result
+    b.max_bits = c.take<unsigned>(64);
+    b.counters = reinterpret_cast<int32_t*>(b.max_bits) + 4;
+    b.out = b.counters + 2 + kSelectRounds + 2;
+    b.sort_bytes = sort_temp_bytes(cap);
+    b.sort_temp = c.take<char>(b.sort_bytes);
+    return b;
+}
+
+// Enqueues the whole detection; the result (count, candidates, overflow) lands in b.out.
+int run_corners(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size_t stride, int max_corners, double quality,
+                double min_distance, float* d_corners, int cap_out, int cap, const CornerBuffers& b) {
+    CornerArgs a{};
+    a.img = d_img;
+    a.w = w;
+    a.h = h;
+    a.stride = stride;
+    a.eig = b.eig;
+    a.max_bits = b.max_bits;
+    a.keys = b.keys;
+    a.sorted = b.sorted;
+    a.rank = b.rank;
+    a.state = b.state;
+    a.counters = b.counters;
+    a.cap = cap;
+    a.quality = quality;
+    a.min_distance = min_distance;
+    a.max_corners = max_corners;
+    hipStream_t s = ctx->stream;
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.max_bits, 0, 64 * sizeof(unsigned), s));
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.keys, 0, sizeof(unsigned long long) * (size_t)cap, s));
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.rank, 0xff, sizeof(int32_t) * (size_t)w * h, s));
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.state, 0, sizeof(int32_t) * (size_t)cap, s));
+    {
+        KernelTimer timer(ctx, KID_CORNER_EIG);
+        hipLaunchKernelGGL(corner_eig_kernel, dim3((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH), dim3(256), 0,
+                           s, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    if (w > 2 && h > 2) {
+        KernelTimer timer(ctx, KID_CORNER_PICK);
+        hipLaunchKernelGGL(corner_pick_kernel, dim3((w - 2 + 63) / 64, (h - 2 + 3) / 4), dim3(256), 0, s, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    {
+        KernelTimer timer(ctx, KID_CORNER_SORT);
+        size_t bytes = b.sort_bytes;
+        SFM_HIP_CHECK(ctx, rocprim::radix_sort_keys_desc(b.sort_temp, bytes, b.keys, b.sorted, (size_t)cap, 0, 64, s));
+    }
+    {
+        KernelTimer timer(ctx, KID_CORNER_SELECT);
+        hipLaunchKernelGGL(corner_rank_kernel, dim3(256), dim3(256), 0, s, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+        for (int r = 0; r < kSelectRounds; ++r) {
+            hipLaunchKernelGGL(corner_select_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, s, a, r);
+            SFM_HIP_CHECK(ctx, hipGetLastError());
+        }
+        hipLaunchKernelGGL(corner_settle_kernel, dim3(1), dim3(64), 0, s, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(corner_emit_kernel, dim3(1), dim3(1024), 0, s, a, reinterpret_cast<float2*>(d_corners),
+                           cap_out, b.out);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return SFM_OK;
+}
+
+int check_corner_args(sfm_ctx* ctx, const void* img, int w, int h, size_t stride, double quality,
+                      double min_distance, const void* corners, int cap_out) {
+    if (!img || (!corners && cap_out > 0)) return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (w < 3 || h < 3 || stride < (size_t)w || (size_t)w * h > 0x7fffffffu)
+        return set_error(ctx, SFM_E_INVALID, "image must be at least 3x3, stride >= width, below 2^31 pixels");
+    // OpenCV: CV_Assert(qualityLevel > 0 && minDistance >= 0 && maxCorners >= 0)
+    if (!(quality > 0) || !(min_distance >= 0) || cap_out < 0)
+        return set_error(ctx, SFM_E_INVALID, "qualityLevel must be > 0, minDistance and the capacity >= 0");
+    if (min_distance > 1024) return set_error(ctx, SFM_E_INVALID, "minDistance above 1024 is not supported");
+    return SFM_OK;
+}
+
+}  // namespace
+
+}  // namespace sfm
+
+using namespace sfm;
+
+extern "C" {
+
+size_t sfm_good_features_workspace(int w, int h, int max_candidates) {
+    if (w <= 0 || h <= 0) return 0;
+    const int cap = max_candidates > 0 ? max_candidates : default_capacity(w, h);
+    Carver c(nullptr);
+    carve_corners(c, w, h, cap);
+    return c.total();
+}
+
+int sfm_good_features_dev(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size_t stride, int max_corners,
+                          double quality, double min_distance, int max_candidates, float* d_corners, int cap,
+                          int32_t* d_info) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    SFM_RETURN_IF(check_corner_args(ctx, d_img, w, h, stride, quality, min_distance, d_corners, cap));
+    if (!d_info || max_corners < 0) return set_error(ctx, SFM_E_INVALID, "d_info is NULL or maxCorners negative");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const int cand_cap = max_candidates > 0 ? std::min<size_t>(max_candidates, (size_t)w * h) : default_capacity(w, h);
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, sfm_good_features_workspace(w, h, cand_cap), &ws));
+    Carver c(ws);
+    const CornerBuffers b = carve_corners(c, w, h, cand_cap);
+    SFM_RETURN_IF(run_corners(ctx, d_img, w, h, stride, max_corners, quality, min_distance, d_corners, cap, cand_cap, b));
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_info, b.out, 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    return SFM_OK;
+}
+
+int sfm_good_features(sfm_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, int max_corners, double quality,
+                      double min_distance, float* corners, int cap, int* count) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (count) *count = 0;
+    SFM_RETURN_IF(check_corner_args(ctx, img, w, h, stride, quality, min_distance, corners, cap));
+    if (!count || max_corners < 0) return set_error(ctx, SFM_E_INVALID, "count is NULL or maxCorners negative");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    Carver sz(nullptr);
+    sz.take<uint8_t>((size_t)w * h);
+    sz.take<float>(2 * (size_t)std::max(cap, 1));
+    sz.take<int32_t>(4);
+    void* st;
+    SFM_RETURN_IF(staging(ctx, sz.total(), &st));
+    Carver sc(st);
+    uint8_t* d_img = sc.take<uint8_t>((size_t)w * h);
+    float* d_corners = sc.take<float>(2 * (size_t)std::max(cap, 1));
+    int32_t* d_info = sc.take<int32_t>(4);
+    SFM_RETURN_IF(upload_rows(ctx, d_img, img, stride, (size_t)w, (size_t)h));
+    int32_t info[3] = {0, 0, 0};
+    // first with the usual candidate capacity; an image of plateaus can need every pixel
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int cand_cap = attempt == 0 ? 0 : (int)std::min<size_t>((size_t)w * h, 0x7fffffff);
+        SFM_RETURN_IF(sfm_good_features_dev(ctx, d_img, w, h, (size_t)w, max_corners, quality, min_distance, cand_cap,
+                                            d_corners, cap, d_info));
+        SFM_HIP_CHECK(ctx, hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
+        SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (!info[2]) break;
+    }
+    ctx->pinned_used = 0;
+    if (info[2]) return set_error(ctx, SFM_E_INVALID, "candidate capacity exceeded");
+    if (info[0] > 0)
+        SFM_HIP_CHECK(ctx, hipMemcpy(corners, d_corners, sizeof(float) * 2 * (size_t)info[0], hipMemcpyDeviceToHost));
+    *count = info[0];
+    return SFM_OK;
+}
+
+int sfm_min_eigen_val_dev(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size_t stride, float* d_eig) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (!d_img || !d_eig) return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (w < 3 || h < 3 || stride < (size_t)w || (size_t)w * h > 0x7fffffffu)
+        return set_error(ctx, SFM_E_INVALID, "image must be at least 3x3, stride >= width, below 2^31 pixels");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, 256, &ws));
+    CornerArgs a{};
+    a.img = d_img;
+    a.w = w;
+    a.h = h;
+    a.stride = stride;
+    a.eig = d_eig;
+    a.max_bits = static_cast<unsigned*>(ws);
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(ws, 0, 256, ctx->stream));
+    KernelTimer timer(ctx, KID_CORNER_EIG);
+    hipLaunchKernelGGL(corner_eig_kernel, dim3((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH), dim3(256), 0,
+                       ctx->stream, a);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+}  // extern "C"

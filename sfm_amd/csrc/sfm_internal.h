@@ -34,6 +34,10 @@ enum KernelId {
     KID_FM_SOLVE,
     KID_FM_SCORE,
     KID_FM_SELECT,
+    KID_CORNER_EIG,
+    KID_CORNER_PICK,
+    KID_CORNER_SORT,
+    KID_CORNER_SELECT,
     KID_COUNT
 };
 struct TimedLaunch {

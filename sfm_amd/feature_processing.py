@@ -23,6 +23,28 @@ def default_context():
     return _default_ctx
 
 
+class FeatureDetector:
+    """Source Files/feature_processing.cpp:3-99, the part on the tracker's path: the Shi-Tomasi
+    corners generateFlowFeatures hands to OptFlow::computeFlow.  The key point detectors and
+    descriptor extractors of generateFeatures (AKAZE, ORB, SIFT ...) are OpenCV's and are not
+    provided."""
+
+    def __init__(self, method="AKAZE", ctx=None):
+        self.method = str(method).upper()
+        self.ctx = ctx if ctx is not None else default_context()
+
+    def generateFeatures(self, imGray):
+        raise capi.SfmError("key point detection / description is not part of sfm_hip "
+                            "(Source Files/feature_processing.cpp:78-85 stays with OpenCV)")
+
+    def generateFlowFeatures(self, imGray, corners, maxCorners, qualityLevel, minDistance):
+        """feature_processing.cpp:87-99: cv::goodFeaturesToTrack, appended to `corners`
+        (good points already there are kept).  Returns the extended float32 [n, 2] array."""
+        found = self.ctx.good_features(imGray, int(maxCorners), float(qualityLevel), float(minDistance))
+        have = np.asarray(corners, dtype=np.float32).reshape(-1, 2)
+        return np.concatenate([have, found], axis=0)
+
+
 class DescriptorMatcher:
     """Source Files/feature_processing.cpp:101-226."""
 

@@ -423,11 +423,99 @@ def gen_lk():
     np.savez_compressed(os.path.join(HERE, "lk.npz"), **out)
 
 
+# --------------------------------------------------------------------------
+# Shi-Tomasi corners (goodFeaturesToTrack)
+# --------------------------------------------------------------------------
+def np_min_eigen_val(img):
+    """cornerMinEigenVal(img, 3, 3) in float32, whole-array NumPy: Sobel with the scale
+    1 / (4 * 3 * 255) folded into the smoothing taps, products, 3x3 box sum (rows first),
+    smaller eigenvalue.  Borders: reflect-101 == numpy 'reflect'."""
+    h, w = img.shape
+    k1 = F32(1.0 / (4.0 * 3.0 * 255.0))
+    k0 = F32(2.0 / (4.0 * 3.0 * 255.0))
+    p = np.pad(img.astype(np.int32), 1, mode="reflect")
+    up, mid, dn = p[:-2], p[1:-1], p[2:]
+    # Dx: horizontal difference (exact integers), vertical [1 2 1] * scale
+    diff = lambda r: (r[:, 2:] - r[:, :-2]).astype(F32)
+    dx = (diff(up) + diff(dn)) * k1 + diff(mid) * k0
+    # Dy: horizontal [1 2 1] * scale, vertical difference
+    smooth = lambda r: (r[:, 2:] + r[:, :-2]).astype(F32) * k1 + r[:, 1:-1].astype(F32) * k0
+    dy = smooth(dn) - smooth(up)
+    out = []
+    for prod in (dx * dx, dx * dy, dy * dy):
+        q = np.pad(prod.astype(F32), 1, mode="reflect")
+        rows = (q[:, :-2] + q[:, 1:-1]) + q[:, 2:]
+        out.append((rows[:-2] + rows[1:-1]) + rows[2:])
+    a, b, c = out[0] * F32(0.5), out[1], out[2] * F32(0.5)
+    return ((a + c) - np.sqrt((a - c) * (a - c) + b * b)).astype(F32)
+
+
+def np_good_features(img, max_corners, quality, min_distance):
+    h, w = img.shape
+    eig = np_min_eigen_val(img)
+    thresh = F32(np.float64(eig.max()) * quality)
+    eig = np.where(eig > thresh, eig, F32(0))
+    inner = eig[1:-1, 1:-1]
+    dil = np.max([eig[1 + j:h - 1 + j, 1 + i:w - 1 + i] for j in (-1, 0, 1) for i in (-1, 0, 1)], axis=0)
+    ys, xs = np.nonzero((inner != 0) & (inner == dil))
+    ys, xs = ys + 1, xs + 1
+    vals = eig[ys, xs]
+    pos = ys * w + xs
+    order = np.lexsort((-pos, -vals.astype(np.float64)))   # value descending, then address descending
+    ys, xs = ys[order], xs[order]
+    kept = []
+    if min_distance >= 1:
+        cell = int(np.rint(min_distance))      # cvRound: half to even, like rint
+        md2 = min_distance * min_distance
+        for x, y in zip(xs, ys):
+            ok = True
+            for (ax, ay) in kept:
+                if abs(ax // cell - x // cell) <= 1 and abs(ay // cell - y // cell) <= 1:
+                    ddx, ddy = F32(x) - F32(ax), F32(y) - F32(ay)
+                    if np.float64(F32(ddx * ddx + ddy * ddy)) < md2:
+                        ok = False
+                        break
+            if ok:
+                kept.append((int(x), int(y)))
+                if max_corners > 0 and len(kept) == max_corners:
+                    break
+    else:
+        kept = [(int(x), int(y)) for x, y in zip(xs, ys)]
+        if max_corners > 0:
+            kept = kept[:max_corners]
+    return np.array(kept, F32).reshape(-1, 2), len(order)
+
+
+def gen_corners():
+    rng = np.random.default_rng(77)
+    out = {}
+    a = to_u8(texture(rng, 60, 80))
+    b = rng.integers(0, 256, size=(33, 47), dtype=np.uint8)
+    c = np.zeros((24, 40), np.uint8)          # two identical blobs: equal strengths, tie order
+    c[5:9, 6:10] = 200
+    c[5:9, 26:30] = 200
+    c[15:19, 16:20] = 90
+    d = np.full((9, 11), 37, np.uint8)        # constant image: no corner at all
+    cases = {"a": (a, 50, 0.01, 5.0), "a_all": (a, 0, 0.05, 3.0), "a_frac": (a, 0, 0.01, 2.5),
+             "a_nodist": (a, 25, 0.2, 0.0), "b": (b, 30, 0.1, 4.0), "c": (c, 0, 0.01, 6.0),
+             "d": (d, 10, 0.01, 3.0)}
+    for name, (img, mc, q, md) in cases.items():
+        pts, ncand = np_good_features(img, mc, q, md)
+        out[f"img_{name}"] = img
+        out[f"args_{name}"] = np.array([mc, q, md], np.float64)
+        out[f"pts_{name}"] = pts
+        out[f"ncand_{name}"] = np.array([ncand])
+    out["eig_a"] = np_min_eigen_val(a)
+    out["eig_b"] = np_min_eigen_val(b)
+    np.savez_compressed(os.path.join(HERE, "corners.npz"), **out)
+
+
 if __name__ == "__main__":
-    gen_hamming()
-    gen_l2()
-    gen_triangulate()
-    gen_lk()
+    import sys
+
+    todo = sys.argv[1:] or ["hamming", "l2", "triangulate", "lk", "corners"]
+    for name in todo:
+        globals()["gen_" + name]()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

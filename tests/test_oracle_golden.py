@@ -237,3 +237,21 @@ def test_oracle_fundamental_recovers_geometry(oracle):
     # fewer than 7 points: nothing found, mask untouched
     found, _, mask, _ = oracle.find_fundamental(p1[:6], p2[:6])
     assert not found and (mask == 0).all()
+
+
+def test_min_eigen_val_golden(oracle):
+    """cornerMinEigenVal restated in C against the independent whole-array NumPy version."""
+    g = load_golden("corners.npz")
+    for name in ("a", "b"):
+        assert np.array_equal(oracle.min_eigen_val(g[f"img_{name}"]), g[f"eig_{name}"])
+
+
+@pytest.mark.parametrize("name", ["a", "a_all", "a_frac", "a_nodist", "b", "c", "d"])
+def test_good_features_golden(oracle, name):
+    """goodFeaturesToTrack: threshold, local maxima, order (ties by address), grid-limited
+    minimum distance incl. a fractional one, maxCorners, no distance filter, constant image."""
+    g = load_golden("corners.npz")
+    mc, q, md = g[f"args_{name}"]
+    pts, ncand = oracle.good_features(g[f"img_{name}"], int(mc), q, md, return_candidates=True)
+    assert ncand == int(g[f"ncand_{name}"][0])
+    assert np.array_equal(pts, g[f"pts_{name}"])
