@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="framepair", choices=["framepair", "c3", "c4", "c5", "f1"])
+    ap.add_argument("--workload", default="framepair", choices=["framepair", "c3", "c4", "c5", "f1", "f3"])
     ap.add_argument("--pairs", type=int, default=32, help="frame pairs per rank and step")
     ap.add_argument("--frames", type=int, default=512, help="c5: frames in the window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -591,10 +591,86 @@ def run_f1(args, rank, world, local):
     return out
 
 
+# --------------------------------------------------------------------------- f3 corners
+def run_f3(args, rank, world, local):
+    """Shi-Tomasi corners (goodFeaturesToTrack, feature_processing.cpp:87-99) on P device-resident
+    1280x720 frames per step, with the reference application's settings (2000 corners, quality
+    0.01, minimum distance 10)."""
+    import torch
+
+    from sfm_amd import capi, synth
+
+    dev = torch.device("cuda", local)
+    P = args.pairs
+    MAXC, QUAL, MIND = 2000, 0.01, 10.0
+    ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
+    n_tex = min(4, P)
+    frames = np.stack([synth.to_u8(synth.texture(LK_H, LK_W, seed=42 + 17 * i + 1000 * rank))
+                       for i in range(n_tex)])
+    d_frames = torch.from_numpy(frames).to(dev)
+    d_pts = torch.zeros((P, MAXC, 2), dtype=torch.float32, device=dev)
+    d_info = torch.zeros((P, 3), dtype=torch.int32, device=dev)
+    ctx.reserve(capi.Context.good_features_workspace(LK_W, LK_H))
+
+    def step():
+        for p in range(P):
+            ctx.good_features_dev(d_frames[p % n_tex], LK_W, LK_H, LK_W, MAXC, QUAL, MIND, d_pts[p], MAXC,
+                                  d_info[p])
+
+    dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, ctx)
+    info = d_info.cpu().numpy()
+    eig_ms, eig_n = prof.get("corner_eig_kernel", (0.0, 0))
+    px = LK_W * LK_H
+    out = {
+        "metric": "frames/sec of Shi-Tomasi corner detection (goodFeaturesToTrack, 1280x720)",
+        "value": round(world * P * args.steps / dt, 1), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"f3: goodFeaturesToTrack on {P} frames {LK_W}x{LK_H}/rank/step, "
+                               f"maxCorners {MAXC}, quality {QUAL}, minDistance {MIND}"},
+        "ms_per_frame": round(1e3 * dt / args.steps / P, 4),
+        "kernels": {k: kernel_line(prof, k) for k in sorted(prof)},
+        "check": {"corners_per_frame": int(info[:, 0].mean()), "candidates_per_frame": int(info[:, 1].mean()),
+                  "overflow": int(info[:, 2].max())},
+    }
+    if eig_n:
+        avg_s = eig_ms / eig_n * 1e-3
+        # the strength map is the one full-image pass: 1 B per pixel in, 4 B per pixel out
+        out["roofline"] = {"kernel": "corner_eig_kernel", "bound": "hbm",
+                           "achieved": round(5.0 * px / avg_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(5.0 * px / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+                           "avg_launch_us": round(avg_s * 1e6, 2), "traffic": None,
+                           "algorithmic_per_launch": f"5 B x {px} pixels = {5 * px / 1e6:.2f} MB "
+                                                     f"(u8 image in, float strength map out)"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle
+
+        t0 = time.perf_counter()
+        reps, same = 0, True
+        while True:
+            want = pyoracle.good_features(frames[reps % n_tex], MAXC, QUAL, MIND)
+            if reps < n_tex:
+                got = d_pts[reps].cpu().numpy()[: info[reps, 0]]
+                same = same and np.array_equal(got, want)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > 8.0 and reps >= n_tex:
+                break
+        out["cpu_baseline"] = {"value": round(reps / el, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": f"{reps} frames of the same set in {el:.1f} s, one thread, "
+                                         f"restatement not OpenCV",
+                               "ms_per_frame": round(1e3 * el / reps, 3)}
+        out["check"]["identical_to_cpu"] = bool(same)
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    ctx.close()
+    return out
+
+
 def main():
     args = parse()
     rank, world, local = dist_setup(args.gpus)
-    run = {"framepair": run_framepair, "c3": run_c3, "c4": run_c4, "c5": run_c5, "f1": run_f1}[args.workload]
+    run = {"framepair": run_framepair, "c3": run_c3, "c4": run_c4, "c5": run_c5, "f1": run_f1, "f3": run_f3}[args.workload]
     out = run(args, rank, world, local)
     if rank == 0:
         print(json.dumps(out))

@@ -8,22 +8,31 @@
 //                            appended as sortable keys (value bits << 32 | y * w + x).
 //   3. radix sort, descending: by value, ties by address, both descending, as OpenCV's
 //      std::sort with greaterThanPtr orders its pointers.
-//   4. corner_rank_kernel    position -> rank image.
+//   4. corner_rank_kernel    position -> rank image (which also carries each candidate's state).
 //   5. corner_select_kernel  the greedy minimum-distance pass.  Sequentially, a candidate is
-//                            kept unless an already kept one in the 3x3 grid cells around it is
-//                            closer than minDistance.  Here every undecided candidate looks at
-//                            the stronger candidates in its window each round: one of them kept
-//                            -> dropped; all of them dropped -> kept; otherwise it waits.  A
-//                            decision is only ever taken on final information, so the fixed
-//                            point is the sequential answer whatever the schedule; rounds that
-//                            find nothing left exit at once, and a single-wave sequential pass
-//                            settles whatever a fixed number of rounds left open.
+//                            kept unless an already kept one is closer than minDistance (the
+//                            grid of round(minDistance) cells OpenCV searches never hides such a
+//                            corner: ceil(d) - 1 <= round(d), so it lies in the 3x3 cells).
+//                            Here every undecided candidate looks at the stronger candidates
+//                            in its disc each round: one of them kept -> dropped; all of them
+//                            dropped -> kept; otherwise it waits.  A decision is only ever
+//                            taken on final information, so the fixed point is the sequential
+//                            answer whatever the schedule.  Only a prefix of the sorted
+//                            candidates is worked on (a candidate depends on stronger ones
+//                            only): when a round leaves it settled with fewer than maxCorners
+//                            kept, the next round works on twice as much; with enough kept the
+//                            rounds end.  Every workgroup derives that schedule for itself
+//                            from the per-round counts of the rounds before (no workgroup waits
+//                            on another).  Rounds after the end exit at once; a single-wave
+//                            sequential pass settles whatever a fixed number of rounds left open.
 //   6. corner_emit_kernel    the kept candidates, in rank order, up to maxCorners.
 //
 // All float arithmetic is unfused and ordered as in the CPU restatement: Sobel smoothing
 // (s0 + s2) * k1 + s1 * k0 with the scale 1 / (4 * 3 * 255) folded into the taps, box sums
 // ((l + m) + r) per row then ((top + mid) + bottom), eig = (a + c) - sqrt((a - c)^2 + b^2).
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -36,7 +45,11 @@ namespace sfm {
 namespace {
 
 constexpr int kTileW = 64, kTileH = 16;  // outputs per workgroup of 256 threads
-constexpr int kSelectRounds = 24;
+constexpr int kSelectRounds = 12;
+constexpr int kMaxDistance = 128;  // largest minDistance: the disc's offsets are tabulated
+// per round r: candidates still open after it, candidates kept in it
+enum { C_FOUND = 0, C_OVERFLOW, C_OPEN, C_KEPT = C_OPEN + kSelectRounds, C_COUNT = C_KEPT + kSelectRounds };
+constexpr int kStateShift = 30;  // rank image entries: rank | state << 30, or -1
 
 struct CornerArgs {
     const uint8_t* img;
@@ -46,9 +59,9 @@ struct CornerArgs {
     unsigned* max_bits;     // ordered bits of the image maximum
     unsigned long long* keys;     // [cap] appended candidates
     unsigned long long* sorted;   // [cap]
-    int32_t* rank;          // [h][w], -1 where no candidate
+    int32_t* rank;          // [h][w]: -1 where no candidate, else rank | state << 30
     int32_t* state;         // [cap] 0 undecided, 1 kept, 2 dropped
-    int32_t* counters;      // [0] candidates found, [1] overflow, [2 + r] undecided after round r
+    int32_t* counters;      // see the C_* indices
     int cap;
     double quality, min_distance;
     int max_corners;
@@ -142,121 +155,195 @@ __global__ __launch_bounds__(256) void corner_eig_kernel(CornerArgs a) {
     if (tid == 0 && s_max) atomicMax(a.max_bits, s_max);
 }
 
+constexpr int kPickRows = 32;  // rows per workgroup of the candidate pass (8 per wave)
+
 __global__ __launch_bounds__(256) void corner_pick_kernel(CornerArgs a) {
-    const int x = 1 + blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = 1 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = 1 + blockIdx.x * 64 + lane;
     // minMaxLoc's double maximum times the double quality level, then threshold()'s float
     const float thresh = (float)((double)from_ordered_bits(*a.max_bits) * a.quality);
-    bool pick = false;
-    float v = 0.f;
-    if (x < a.w - 1 && y < a.h - 1) {
-        const float* e = a.eig + (size_t)y * a.w + x;
-        v = e[0] > thresh ? e[0] : 0.f;  // THRESH_TOZERO
-        if (v != 0.f) {
-            float m = v;  // 3x3 dilation of the thresholded image
+    unsigned long long ballots[kPickRows / 4];
+    float vals[kPickRows / 4];
+    int wave_total = 0;
 #pragma unroll
-            for (int j = -1; j <= 1; ++j)
+    for (int k = 0; k < kPickRows / 4; ++k) {
+        const int y = 1 + blockIdx.y * kPickRows + wave + 4 * k;
+        bool pick = false;
+        float v = 0.f;
+        if (x < a.w - 1 && y < a.h - 1) {
+            const float* e = a.eig + (size_t)y * a.w + x;
+            v = e[0] > thresh ? e[0] : 0.f;  // THRESH_TOZERO
+            if (v != 0.f) {
+                float m = v;  // 3x3 dilation of the thresholded image
 #pragma unroll
-                for (int i = -1; i <= 1; ++i) {
-                    const float u = e[j * a.w + i];
-                    m = fmaxf(m, u > thresh ? u : 0.f);
-                }
-            pick = v == m;
+                for (int j = -1; j <= 1; ++j)
+#pragma unroll
+                    for (int i = -1; i <= 1; ++i) {
+                        const float u = e[j * a.w + i];
+                        m = fmaxf(m, u > thresh ? u : 0.f);
+                    }
+                pick = v == m;
+            }
         }
+        vals[k] = v;
+        ballots[k] = __ballot(pick);
+        wave_total += (int)__popcll(ballots[k]);
     }
-    const unsigned long long ballot = __ballot(pick);
-    if (!ballot) return;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(a.counters, (int)__popcll(ballot));
-    base = __shfl(base, 0);
-    if (pick) {
-        const int slot = base + (int)__popcll(ballot & ((1ULL << lane) - 1ULL));
-        if (slot < a.cap)
-            a.keys[slot] = ((unsigned long long)ordered_bits(v) << 32) | (unsigned)(y * a.w + x);
-        else
-            a.counters[1] = 1;
+    if (lane == 0) s_wave[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = total ? atomicAdd(a.counters + C_FOUND, total) : 0;  // one per workgroup
+    }
+    __syncthreads();
+    int base = s_base;
+    for (int w = 0; w < wave; ++w) base += s_wave[w];
+#pragma unroll
+    for (int k = 0; k < kPickRows / 4; ++k) {
+        const int y = 1 + blockIdx.y * kPickRows + wave + 4 * k;
+        if ((ballots[k] >> lane) & 1ULL) {
+            const int slot = base + (int)__popcll(ballots[k] & ((1ULL << lane) - 1ULL));
+            if (slot < a.cap)
+                a.keys[slot] = ((unsigned long long)ordered_bits(vals[k]) << 32) | (unsigned)(y * a.w + x);
+            else
+                a.counters[C_OVERFLOW] = 1;
+        }
+        base += (int)__popcll(ballots[k]);
     }
 }
 
-__device__ __forceinline__ int candidate_count(const CornerArgs& a) { return min(a.counters[0], a.cap); }
+__device__ __forceinline__ int candidate_count(const CornerArgs& a) { return min(a.counters[C_FOUND], a.cap); }
 
 // States are read and written past the per-CU cache: a wave may then see decisions other
 // waves took earlier in the same launch.  A stale read can only show "undecided", which
-// delays a decision and never changes it.
+// delays a decision and never changes it.  A candidate's state is kept twice: by rank (to
+// walk the candidates) and inside the rank image (so that looking at a neighbouring pixel
+// is one load, not a chain of two).
 __device__ __forceinline__ int load_state(const CornerArgs& a, int i) {
     return __hip_atomic_load(a.state + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void store_state(const CornerArgs& a, int i, int s) {
+__device__ __forceinline__ void store_state(const CornerArgs& a, int i, unsigned pos, int s) {
     __hip_atomic_store(a.state + i, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.rank + pos, i | (s << kStateShift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void corner_rank_kernel(CornerArgs a) {
+// Ranks and the first prefix to work on.
+__global__ __launch_bounds__(256) void corner_rank_kernel(CornerArgs a) {
     const int n = candidate_count(a);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        a.rank[(unsigned)(a.sorted[i] & 0xffffffffu)] = i;
+    const int t0 = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (int i = t0; i < n; i += nt) a.rank[(unsigned)(a.sorted[i] & 0xffffffffu)] = i;
+}
+
+// The disc "closer than minDistance" on the pixel grid.  OpenCV tests float dx*dx + dy*dy <
+// minDistance^2 (a double); for integer offsets the sum is exact, so that is
+// dx*dx + dy*dy <= limit with limit the largest integer below minDistance^2.
+struct Disc {
+    int reach, side, limit;
+    float inv_side;
+};
+__device__ __forceinline__ Disc make_disc(double min_distance) {
+    Disc d;
+    d.reach = max((int)ceil(min_distance) - 1, 0);
+    d.side = 2 * d.reach + 1;
+    d.limit = (int)ceil(min_distance * min_distance) - 1;
+    d.inv_side = 1.0f / (float)d.side;
+    return d;
 }
 
 // Decision for candidate i from the states of the stronger candidates around it:
 // 1 kept, 2 dropped, 0 cannot be told yet.  By one wave.
-__device__ int decide(const CornerArgs& a, int i, int lane, int cell, int reach) {
-    const unsigned pos = (unsigned)(a.sorted[i] & 0xffffffffu);
+__device__ int decide(const CornerArgs& a, int i, unsigned pos, int lane, const Disc& d) {
     const int y = (int)(pos / (unsigned)a.w), x = (int)(pos - (unsigned)y * a.w);
-    const int xc = x / cell, yc = y / cell;
-    const int side = 2 * reach + 1;
-    const double md2 = a.min_distance * a.min_distance;
-    bool dropped = false, waiting = false;
-    for (int t = lane; t < side * side; t += 64) {
-        const int dy = t / side - reach, dx = t - (dy + reach) * side - reach;
-        const int nx = x + dx, ny = y + dy;
-        if (nx < 0 || ny < 0 || nx >= a.w || ny >= a.h) continue;
-        const int j = a.rank[(size_t)ny * a.w + nx];
-        if (j < 0 || j >= i) continue;
-        // the accepted corner is only met if its cell is one of the 3x3 around this one
-        const int cxd = nx / cell - xc, cyd = ny / cell - yc;
-        if (cxd < -1 || cxd > 1 || cyd < -1 || cyd > 1) continue;
-        const float fx = (float)x - (float)nx, fy = (float)y - (float)ny;
-        if (!((double)(fx * fx + fy * fy) < md2)) continue;
-        const int s = load_state(a, j);
-        dropped |= s == 1;
-        waiting |= s == 0;
+    bool near_kept = false, waiting = false;
+    const int cells = d.side * d.side;
+    // branch-free, eight steps at a time: their loads are independent and overlap
+    for (int t0 = lane; t0 < cells; t0 += 512) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + 64 * u;
+            // t / side: exact, (t + 0.5) / side stays 1 / (2 side) away from every integer
+            const int row = (int)(((float)t + 0.5f) * d.inv_side);
+            const int dy = row - d.reach, dx = t - row * d.side - d.reach;
+            const int nx = x + dx, ny = y + dy;
+            const bool look = t < cells && dx * dx + dy * dy <= d.limit && nx >= 0 && ny >= 0 && nx < a.w && ny < a.h;
+            const int got = __hip_atomic_load(a.rank + (size_t)min(max(ny, 0), a.h - 1) * a.w + min(max(nx, 0), a.w - 1),
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[u] = look ? got : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool stronger = v[u] >= 0 && (v[u] & ((1 << kStateShift) - 1)) < i;
+            const int s = v[u] >> kStateShift;
+            near_kept |= stronger && s == 1;
+            waiting |= stronger && s == 0;
+        }
     }
-    if (__any(dropped)) return 2;
+    if (__any(near_kept)) return 2;
     if (__any(waiting)) return 0;
     return 1;
 }
 
+// The prefix of the sorted candidates round `round` works on, or 0 when the rounds have ended:
+// replayed from what the earlier rounds counted.
+__device__ int window_of_round(const CornerArgs& a, int n, int round) {
+    int window = a.max_corners > 0 ? min(n, max(4 * a.max_corners, 1024)) : n;
+    int kept = 0;
+    for (int q = 0; q < round; ++q) {
+        kept += a.counters[C_KEPT + q];
+        if (a.counters[C_OPEN + q] != 0) continue;  // not settled: same prefix again
+        if (window >= n || (a.max_corners > 0 && kept >= a.max_corners)) return 0;
+        window = min(n, 2 * window);
+    }
+    return window;
+}
+
 __global__ __launch_bounds__(256) void corner_select_kernel(CornerArgs a, int round) {
+    __shared__ int s_open, s_kept;
     const int n = candidate_count(a);
-    if (round > 0 && a.counters[2 + round - 1] == 0) return;  // settled in an earlier round
+    const int window = window_of_round(a, n, round);
+    if (window == 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-    const int cell = max((int)rint(a.min_distance), 1);
-    const int reach = max((int)ceil(a.min_distance) - 1, 0);
-    int open = 0;
-    for (int i = wave; i < n; i += n_waves) {
+    const Disc disc = make_disc(a.min_distance);
+    if (threadIdx.x == 0) s_open = s_kept = 0;
+    __syncthreads();
+    int open = 0, kept = 0;
+    for (int i = wave; i < window; i += n_waves) {
         if (load_state(a, i) != 0) continue;
-        const int s = a.min_distance >= 1 ? decide(a, i, lane, cell, reach) : 1;
-        if (s == 0)
-            ++open;
-        else if (lane == 0)
-            store_state(a, i, s);
+        const unsigned pos = (unsigned)(a.sorted[i] & 0xffffffffu);
+        const int s = a.min_distance >= 1 ? decide(a, i, pos, lane, disc) : 1;
+        open += s == 0;
+        kept += s == 1;
+        if (s != 0 && lane == 0) store_state(a, i, pos, s);
     }
-    if (lane == 0 && open) atomicAdd(a.counters + 2 + round, open);
+    if (lane == 0 && open) atomicAdd(&s_open, open);
+    if (lane == 0 && kept) atomicAdd(&s_kept, kept);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (s_open) atomicAdd(a.counters + C_OPEN + round, s_open);
+    if (s_kept) atomicAdd(a.counters + C_KEPT + round, s_kept);
 }
 
 // Whatever the rounds left open, in order, by one wave.
 __global__ __launch_bounds__(64) void corner_settle_kernel(CornerArgs a) {
-    if (a.counters[2 + kSelectRounds - 1] == 0) return;
     const int n = candidate_count(a);
+    if (window_of_round(a, n, kSelectRounds) == 0) return;
     const int lane = threadIdx.x;
-    const int cell = max((int)rint(a.min_distance), 1);
-    const int reach = max((int)ceil(a.min_distance) - 1, 0);
+    const Disc disc = make_disc(a.min_distance);
+    int kept = 0;
     for (int i = 0; i < n; ++i) {
-        if (load_state(a, i) != 0) continue;
-        const int s = decide(a, i, lane, cell, reach);  // every stronger candidate is settled
-        if (lane == 0) store_state(a, i, s);
-        __threadfence();
+        int s = load_state(a, i);
+        if (s == 0) {
+            const unsigned pos = (unsigned)(a.sorted[i] & 0xffffffffu);
+            s = a.min_distance >= 1 ? decide(a, i, pos, lane, disc) : 1;  // every stronger one is settled
+            if (lane == 0) store_state(a, i, pos, s);
+            __threadfence();
+        }
+        kept += s == 1;
+        if (a.max_corners > 0 && kept >= a.max_corners) break;
     }
 }
 
@@ -295,8 +382,8 @@ __global__ __launch_bounds__(1024) void corner_emit_kernel(CornerArgs a, float2*
     }
     if (tid == 0) {
         out[0] = min(running, limit);
-        out[1] = a.counters[0];
-        out[2] = a.counters[1];
+        out[1] = a.counters[C_FOUND];
+        out[2] = a.counters[C_OVERFLOW];
     }
 }
 
@@ -337,7 +424,8 @@ CornerBuffers carve_corners(Carver& c, int w, int h, int cap) {
     // one block to clear: maximum, counters, result
     b.max_bits = c.take<unsigned>(64);
     b.counters = reinterpret_cast<int32_t*>(b.max_bits) + 4;
-    b.out = b.counters + 2 + kSelectRounds + 2;
+    b.out = b.counters + C_COUNT;
+    static_assert(4 + C_COUNT + 3 <= 64, "the cleared block is 64 words");
     b.sort_bytes = sort_temp_bytes(cap);
     b.sort_temp = c.take<char>(b.sort_bytes);
     return b;
@@ -375,7 +463,8 @@ int run_corners(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size_t stride,
     }
     if (w > 2 && h > 2) {
         KernelTimer timer(ctx, KID_CORNER_PICK);
-        hipLaunchKernelGGL(corner_pick_kernel, dim3((w - 2 + 63) / 64, (h - 2 + 3) / 4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(corner_pick_kernel, dim3((w - 2 + 63) / 64, (h - 2 + kPickRows - 1) / kPickRows), dim3(256), 0,
+                           s, a);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
     {
@@ -408,7 +497,7 @@ int check_corner_args(sfm_ctx* ctx, const void* img, int w, int h, size_t stride
     // OpenCV: CV_Assert(qualityLevel > 0 && minDistance >= 0 && maxCorners >= 0)
     if (!(quality > 0) || !(min_distance >= 0) || cap_out < 0)
         return set_error(ctx, SFM_E_INVALID, "qualityLevel must be > 0, minDistance and the capacity >= 0");
-    if (min_distance > 1024) return set_error(ctx, SFM_E_INVALID, "minDistance above 1024 is not supported");
+    if (min_distance > kMaxDistance) return set_error(ctx, SFM_E_INVALID, "minDistance above 128 is not supported");
     return SFM_OK;
 }
 
@@ -435,7 +524,8 @@ int sfm_good_features_dev(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size
     SFM_RETURN_IF(check_corner_args(ctx, d_img, w, h, stride, quality, min_distance, d_corners, cap));
     if (!d_info || max_corners < 0) return set_error(ctx, SFM_E_INVALID, "d_info is NULL or maxCorners negative");
     SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const int cand_cap = max_candidates > 0 ? std::min<size_t>(max_candidates, (size_t)w * h) : default_capacity(w, h);
+    int cand_cap = max_candidates > 0 ? (int)std::min<size_t>(max_candidates, (size_t)w * h) : default_capacity(w, h);
+    cand_cap = std::min(cand_cap, (1 << kStateShift) - 1);  // ranks share a word with the state
     void* ws;
     SFM_RETURN_IF(workspace(ctx, sfm_good_features_workspace(w, h, cand_cap), &ws));
     Carver c(ws);
@@ -472,6 +562,16 @@ int sfm_good_features(sfm_ctx* ctx, const uint8_t* img, int w, int h, size_t str
         SFM_HIP_CHECK(ctx, hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
         SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (!info[2]) break;
+    }
+    if (getenv("SFM_CORNER_TRACE")) {  // the rounds of the selection, for tuning
+        int32_t c[C_COUNT];
+        Carver wc(ctx->ws);
+        const CornerBuffers wb = carve_corners(wc, w, h, default_capacity(w, h));
+        if (hipMemcpy(c, wb.counters, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "corners: found %d open/kept per round:", c[C_FOUND]);
+            for (int r = 0; r < kSelectRounds; ++r) fprintf(stderr, " %d/%d", c[C_OPEN + r], c[C_KEPT + r]);
+            fprintf(stderr, "\n");
+        }
     }
     ctx->pinned_used = 0;
     if (info[2]) return set_error(ctx, SFM_E_INVALID, "candidate capacity exceeded");
