@@ -362,6 +362,33 @@ public:
     }
 };
 
+/* Header Files/feature_processing.h:8-31, the member on the tracker's path:
+ * generateFlowFeatures (Source Files/feature_processing.cpp:87-99).  The key point
+ * detectors / extractors of generateFeatures are OpenCV's own and stay with it: keep the
+ * reference's class for those and forward this one member, or use this class where only
+ * flow features are generated. */
+class FeatureDetector {
+public:
+    Handle handle;
+    explicit FeatureDetector(std::string /*method*/ = "AKAZE", Handle h = Handle::shared()) : handle(h) {}
+
+    /* cv::goodFeaturesToTrack(imGray, _corners, maxCorners, qualityLevel, minDistance);
+     * new corners are appended, points already in `corners` are kept. */
+    void generateFlowFeatures(cvx::Mat& imGray, std::vector<cvx::Point2f>& corners, int maxCorners,
+                              double qualityLevel, double minDistance) {
+        if (!mat_is_u8(imGray) || mat_channels(imGray) != 1) raise("generateFlowFeatures needs an 8-bit single-channel image");
+        if (maxCorners < 0) raise("maxCorners must not be negative");
+        const size_t cap = maxCorners > 0 ? size_t(maxCorners) : size_t(imGray.rows) * size_t(imGray.cols);
+        std::vector<cvx::Point2f> found(cap);
+        int count = 0;
+        handle.check(sfm_good_features(handle.get(), imGray.data, imGray.cols, imGray.rows, mat_step(imGray), maxCorners,
+                                       qualityLevel, minDistance, reinterpret_cast<float*>(found.data()), int(cap),
+                                       &count),
+                     "sfm_good_features");
+        corners.insert(corners.end(), found.begin(), found.begin() + count);
+    }
+};
+
 /* Header Files/reconstruction.h:140-159 (constructor and triangulateCloud).
  * Camera is the reference's CameraParameters (Header Files/camera.h:11-42) or
  * anything else with a K33d member. */

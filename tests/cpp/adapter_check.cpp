@@ -124,6 +124,22 @@ static int run_flow(const char* in, const char* out) {
     return 0;
 }
 
+static int run_corners(const char* in, const char* out) {
+    Reader r(in);
+    const int w_ = r.i32(), h = r.i32(), maxCorners = r.i32();
+    const double quality = r.f64(), minDistance = r.f64();
+    cvx::Mat img(h, w_, cvx::Mat::U8);
+    r.raw(img.data, size_t(h) * w_);
+    sfm_hip::FeatureDetector detector("ORB");
+    sfm_hip::FeatureDetector byValue = detector;  // the reference passes it by value
+    std::vector<cvx::Point2f> corners = {cvx::Point2f(1.5f, 2.5f)};  // kept, new ones are appended
+    byValue.generateFlowFeatures(img, corners, maxCorners, quality, minDistance);
+    Writer w(out);
+    w.i32(int(corners.size()));
+    w.raw(corners.data(), corners.size() * 8);
+    return 0;
+}
+
 struct Camera {  // the part of CameraParameters triangulateCloud reads
     cvx::Matx33d K33d;
 };
@@ -230,6 +246,7 @@ int main(int argc, char** argv) {
         if (argc < 4) { std::fprintf(stderr, "usage: adapter_check match|flow|tri in out | errors\n"); return 2; }
         if (mode == "match") return run_match(argv[2], argv[3]);
         if (mode == "flow") return run_flow(argv[2], argv[3]);
+        if (mode == "corners") return run_corners(argv[2], argv[3]);
         if (mode == "tri") return run_tri(argv[2], argv[3]);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "adapter_check: %s\n", e.what());

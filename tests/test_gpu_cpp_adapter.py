@@ -162,3 +162,15 @@ def test_find_robust_matches_default_epipolar_filter(oracle, tmp_path):
     assert out.i32() == k
     assert np.array_equal(out.arr("<i4", k), want["queryIdx"])
     assert np.array_equal(out.arr("<i4", k), want["trainIdx"])
+
+
+def test_generate_flow_features(oracle, tmp_path):
+    """sfm_hip::FeatureDetector::generateFlowFeatures appends what goodFeaturesToTrack finds."""
+    img = synth.to_u8(synth.texture(240, 320, seed=9))
+    payload = struct.pack("<iiidd", 320, 240, 150, 0.01, 8.0)
+    out = Cursor(run("corners", payload + img.tobytes(), tmp_path))
+    n = out.i32()
+    pts = out.arr("<f4", 2 * n).reshape(n, 2)
+    want = oracle.good_features(img, 150, 0.01, 8.0)
+    assert len(want) == 150
+    assert np.array_equal(pts[0], [1.5, 2.5]) and np.array_equal(pts[1:], want)

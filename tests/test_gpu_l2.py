@@ -126,5 +126,7 @@ def test_matcher_mirror_class(ctx, oracle):
     np.testing.assert_array_equal(pb, kp_b[want["trainIdx"]])
     np.testing.assert_array_equal(ia, want["queryIdx"])
     np.testing.assert_array_equal(ib, want["trainIdx"])
-    with pytest.raises(capi.SfmError):
-        m.findRobustMatches(kp_a, kp_b, a, b, useEpipolarFilter=True)
+    # with the epipolar filter: the oracle's findFundamentalMat mask, applied in order
+    pa, pb, matches, ia, ib = m.findRobustMatches(kp_a, kp_b, a, b, useEpipolarFilter=True)
+    _, _, mask, _ = oracle.find_fundamental(kp_a[want["queryIdx"]], kp_b[want["trainIdx"]])
+    assert _tuples(matches) == _tuples(want[mask.astype(bool)])
