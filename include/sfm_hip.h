@@ -279,6 +279,30 @@ size_t sfm_good_features_workspace(int w, int h, int max_candidates);
  * float, dense. */
 int sfm_min_eigen_val_dev(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size_t stride, float* d_eig);
 
+/* ---- relative pose from tracked points ---------------------------------------------------- */
+
+#define SFM_POSE_RANSAC 0 /* cv::RANSAC */
+#define SFM_POSE_LMEDS 1  /* cv::LMEDS  */
+
+/* cv::findEssentialMat(prevPts, currPts, cameraK, method, prob, threshold, mask) of
+ * Tracking::findCameraPose, Source Files/tracking.cpp:94 (five-point solver in a RANSAC or
+ * LMedS registrator; max_iters 1000 is OpenCV's default).  pts: n (x, y) float pairs in
+ * pixels, host memory; K: 3x3 row-major camera matrix.  E: room for 10 matrices of 9 doubles;
+ * *n_matrices receives how many were written: 1 when a model was found, 0 when none, and
+ * every solution of the direct solve when n == 5 (OpenCV stacks them into a 3k x 3 matrix,
+ * which the reference then rejects).  mask: n bytes, 1 for inliers. */
+int sfm_find_essential(sfm_ctx* ctx, const float* pts1, const float* pts2, int n, const double* K, int method,
+                       double prob, double threshold, int max_iters, double* E, uint8_t* mask, int* n_matrices);
+
+/* Many device-resident point sets per call (problem p at p * problem_stride points; counts
+ * from d_counts or count_uniform).  d_E: [n_problems][10][9] doubles; d_mask:
+ * [n_problems][problem_stride]; d_found: matrices written per problem.  K is read on the host. */
+int sfm_find_essential_dev(sfm_ctx* ctx, const float* d_pts1, const float* d_pts2, size_t problem_stride,
+                           const int32_t* d_counts, int count_uniform, int n_problems, const double* K, int method,
+                           double prob, double threshold, int max_iters, double* d_E, uint8_t* d_mask,
+                           int32_t* d_found);
+size_t sfm_find_essential_workspace(int n_problems, size_t problem_stride, int max_iters);
+
 #ifdef __cplusplus
 }
 #endif

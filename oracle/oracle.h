@@ -14,7 +14,7 @@
  * modules/imgproc/src/pyramids.cpp, modules/calib3d/src/triangulate.cpp,
  * modules/calib3d/src/calibration.cpp, modules/calib3d/src/fundam.cpp,
  * modules/calib3d/src/ptsetreg.cpp, modules/imgproc/src/featureselect.cpp,
- * modules/imgproc/src/corner.cpp) and are anchored on the reference's
+ * modules/imgproc/src/corner.cpp, modules/calib3d/src/five-point.cpp) and are anchored on the reference's
  * own call sites, cited per function as "Source Files/<file>:<line>".
  * They are checked against independently written NumPy vectors under
  * tests/golden/, not against OpenCV itself.
@@ -145,6 +145,34 @@ int orc_fm_subsets(const float* m1, const float* m2, int count, int max_iters, i
                    int32_t* idx);
 /* RANSACUpdateNumIters */
 int orc_ransac_update_num_iters(double p, double ep, int model_points, int max_iters);
+
+/* ---- relative pose --------------------------------------------------------- */
+
+/* EMEstimatorCallback::runKernel of cv::findEssentialMat: five normalised correspondences
+ * (x, y doubles) -> up to ten essential matrices (9 doubles each, unit Frobenius norm). */
+int orc_em_5point(const double* m1, const double* m2, double* ematrix);
+
+/* The index subsets the registrator draws for `count` points: out is [max_iters][5]. */
+int orc_em_subsets(int count, int max_iters, int32_t* out);
+
+/* cv::findEssentialMat(prevPts, currPts, cameraK, method, prob, threshold, mask),
+ * Source Files/tracking.cpp:94.  method 0 = RANSAC, 1 = LMEDS.  Returns the number of 3x3
+ * matrices written to E_out (room for 10): 1 for a found model, several when count == 5
+ * (OpenCV stacks every solution and the reference then rejects the 3k x 3 result), 0 for
+ * none.  mask_out (count bytes) is written as OpenCV writes it. */
+int orc_find_essential(const float* pts1, const float* pts2, int count, const double* K, int method, double prob,
+                       double threshold, int max_iters, double* E_out, uint8_t* mask_out, int* iters_run);
+
+/* cv::decomposeEssentialMat */
+void orc_decompose_essential(const double* E, double* R1, double* R2, double* t);
+
+/* cv::recoverPose(E, prevPts, currPts, cameraK, R, t, mask), Source Files/tracking.cpp:110.
+ * mask_io: inlier mask in (may be NULL), mask of the chosen pose out.  Returns the count. */
+int orc_recover_pose(const double* E, const float* pts1, const float* pts2, int count, const double* K, double* R,
+                     double* t, uint8_t* mask_io);
+
+/* | p1^T K^-T E K^-1 p0 | of the first correspondence, Source Files/tracking.cpp:99-107. */
+double orc_essential_residual(const double* E, const float* p0, const float* p1, const double* K);
 
 /* ---- corner detection ----------------------------------------------------- */
 

@@ -247,3 +247,70 @@ def good_features(img, max_corners, quality, min_distance, return_candidates=Fal
     if return_candidates:
         return out[:n].copy(), ncand.value
     return out[:n].copy()
+
+
+def em_5point(m1, m2):
+    """Five normalised correspondences -> list of essential matrices [k, 3, 3]."""
+    m1 = np.ascontiguousarray(m1, dtype=np.float64).reshape(5, 2)
+    m2 = np.ascontiguousarray(m2, dtype=np.float64).reshape(5, 2)
+    out = np.zeros((10, 9))
+    f = lib().orc_em_5point
+    f.restype = C.c_int
+    n = f(_p(m1), _p(m2), _p(out))
+    return out[:n].reshape(n, 3, 3).copy()
+
+
+def em_subsets(count, max_iters=1000):
+    out = np.zeros((max_iters, 5), np.int32)
+    f = lib().orc_em_subsets
+    f.restype = C.c_int
+    n = f(C.c_int(count), C.c_int(max_iters), _p(out))
+    return out[:n]
+
+
+def find_essential(p1, p2, K, method=0, prob=0.99, threshold=1.0, max_iters=1000):
+    """cv::findEssentialMat: returns (E [k, 3, 3] (k = 1 normally), mask [n] uint8, iterations)."""
+    p1 = np.ascontiguousarray(p1, dtype=np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, dtype=np.float32).reshape(-1, 2)
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+    n = p1.shape[0]
+    E = np.zeros((10, 9))
+    mask = np.zeros(max(n, 1), np.uint8)
+    iters = C.c_int(0)
+    f = lib().orc_find_essential
+    f.restype = C.c_int
+    k = f(_p(p1), _p(p2), C.c_int(n), _p(K), C.c_int(method), C.c_double(prob), C.c_double(threshold),
+          C.c_int(max_iters), _p(E), _p(mask), C.byref(iters))
+    return E[:k].reshape(k, 3, 3).copy(), mask[:n], iters.value
+
+
+def decompose_essential(E):
+    E = np.ascontiguousarray(E, dtype=np.float64).reshape(3, 3)
+    R1, R2, t = np.zeros(9), np.zeros(9), np.zeros(3)
+    lib().orc_decompose_essential(_p(E), _p(R1), _p(R2), _p(t))
+    return R1.reshape(3, 3), R2.reshape(3, 3), t
+
+
+def recover_pose(E, p1, p2, K, mask=None):
+    """cv::recoverPose: returns (count, R, t, mask)."""
+    E = np.ascontiguousarray(E, dtype=np.float64).reshape(3, 3)
+    p1 = np.ascontiguousarray(p1, dtype=np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, dtype=np.float32).reshape(-1, 2)
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+    n = p1.shape[0]
+    R, t = np.zeros(9), np.zeros(3)
+    m = np.ones(max(n, 1), np.uint8) if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).copy()
+    f = lib().orc_recover_pose
+    f.restype = C.c_int
+    cnt = f(_p(E), _p(p1), _p(p2), C.c_int(n), _p(K), _p(R), _p(t), _p(m))
+    return cnt, R.reshape(3, 3), t, m[:n]
+
+
+def essential_residual(E, p0, p1, K):
+    E = np.ascontiguousarray(E, dtype=np.float64).reshape(3, 3)
+    p0 = np.ascontiguousarray(p0, dtype=np.float32).reshape(2)
+    p1 = np.ascontiguousarray(p1, dtype=np.float32).reshape(2)
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+    f = lib().orc_essential_residual
+    f.restype = C.c_double
+    return float(f(_p(E), _p(p0), _p(p1), _p(K)))

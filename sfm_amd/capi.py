@@ -38,6 +38,7 @@ EXPORTS = [
     "sfm_epipolar_filter_pairs_dev", "sfm_epipolar_filter_pairs_workspace",
     "sfm_good_features", "sfm_good_features_dev", "sfm_good_features_workspace",
     "sfm_min_eigen_val_dev",
+    "sfm_find_essential", "sfm_find_essential_dev", "sfm_find_essential_workspace",
 ]
 
 
@@ -64,7 +65,7 @@ def lib():
         l.sfm_ctx_destroy.restype = None
         l.sfm_ctx_destroy.argtypes = [C.c_void_p]
         for name in ("sfm_match_pairs_workspace", "sfm_pyrlk_workspace", "sfm_fundamental_workspace",
-                     "sfm_epipolar_filter_pairs_workspace", "sfm_good_features_workspace"):
+                     "sfm_epipolar_filter_pairs_workspace", "sfm_good_features_workspace", "sfm_find_essential_workspace"):
             if hasattr(l, name):
                 getattr(l, name).restype = C.c_size_t
         _lib = l
@@ -325,6 +326,37 @@ class Context:
     def epipolar_filter_pairs_workspace(n_pairs, cap, max_iters=1000):
         return int(lib().sfm_epipolar_filter_pairs_workspace(C.c_int(n_pairs), C.c_int(cap),
                                                              C.c_int(max_iters)))
+
+    def find_essential(self, pts1, pts2, K, method=0, prob=0.99, threshold=1.0, max_iters=1000):
+        """cv::findEssentialMat(pts1, pts2, K, method, prob, threshold, mask): returns
+        (E [k, 3, 3], mask [n] uint8); k is 1 for a found model, 0 for none, and the number of
+        solutions of the direct solve for exactly five points."""
+        p1 = np.ascontiguousarray(pts1, dtype=np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(pts2, dtype=np.float32).reshape(-1, 2)
+        if p1.shape != p2.shape:
+            raise ValueError("point lists differ in length")
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+        n = p1.shape[0]
+        E = np.zeros((10, 9))
+        mask = np.zeros(max(n, 1), np.uint8)
+        k = C.c_int(0)
+        self.check(lib().sfm_find_essential(self._h, _ptr(p1), _ptr(p2), C.c_int(n), _ptr(K), C.c_int(method),
+                                            C.c_double(prob), C.c_double(threshold), C.c_int(max_iters),
+                                            _ptr(E), _ptr(mask), C.byref(k)))
+        return E[:k.value].reshape(k.value, 3, 3).copy(), mask[:n]
+
+    def find_essential_dev(self, d_pts1, d_pts2, problem_stride, d_counts, count_uniform, n_problems, K,
+                           method, prob, threshold, max_iters, d_E, d_mask, d_found):
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+        self.check(lib().sfm_find_essential_dev(
+            self._h, _ptr(d_pts1), _ptr(d_pts2), C.c_size_t(problem_stride), _ptr(d_counts),
+            C.c_int(count_uniform), C.c_int(n_problems), _ptr(K), C.c_int(method), C.c_double(prob),
+            C.c_double(threshold), C.c_int(max_iters), _ptr(d_E), _ptr(d_mask), _ptr(d_found)))
+
+    @staticmethod
+    def find_essential_workspace(n_problems, problem_stride, max_iters=1000):
+        return int(lib().sfm_find_essential_workspace(C.c_int(n_problems), C.c_size_t(problem_stride),
+                                                      C.c_int(max_iters)))
 
     def good_features(self, img, max_corners, quality, min_distance):
         """cv::goodFeaturesToTrack(img, maxCorners, qualityLevel, minDistance): float32 [n, 2],

@@ -212,7 +212,8 @@ const char* sfm_profile_kernel_name(int kernel_id) {
         "lk_pad_level0_kernel", "lk_pyr_down_kernel", "lk_scharr_kernel", "lk_track_kernel",
         "triangulate_dlt_kernel", "triangulate_list_kernel", "fm_subsets_kernel", "fm_solve_kernel",
         "fm_score_kernel", "fm_select_kernel", "corner_eig_kernel", "corner_pick_kernel",
-        "corner_sort", "corner_select_kernel"};
+        "corner_sort", "corner_select_kernel", "em_advance_kernel", "em_solve_kernel", "em_score_kernel",
+        "pose_kernels"};
     return kernel_id >= 0 && kernel_id < sfm::KID_COUNT ? names[kernel_id] : "";
 }
 

@@ -38,6 +38,10 @@ enum KernelId {
     KID_CORNER_PICK,
     KID_CORNER_SORT,
     KID_CORNER_SELECT,
+    KID_EM_ADVANCE,
+    KID_EM_SOLVE,
+    KID_EM_SCORE,
+    KID_POSE,
     KID_COUNT
 };
 struct TimedLaunch {

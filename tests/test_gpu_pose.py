@@ -1,0 +1,121 @@
+"""GPU parity tests of the relative-pose stage (cv::findEssentialMat and cv::recoverPose as
+called by Tracking::findCameraPose, Source Files/tracking.cpp:91-113) against the CPU oracle.
+
+Parity is unpinned for this stage as for the others (no OpenCV here).  GPU and oracle draw the
+same samples and run the same elimination; the GPU stops the polynomial root iteration once
+its corrections are rounding noise where the oracle (like OpenCV) sweeps 300 times, so the
+candidate matrices agree to ~1e-9, and masks are expected -- and asserted -- to be identical on
+these seeded inputs.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from sfm_amd import capi
+
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def two_view(n, seed, outliers=0.2, sigma=0.5):
+    from sfm_amd import synth
+
+    s = synth.triangulation_set(n, seed=seed, sigma=sigma, outliers=0.0)
+    rng = np.random.default_rng(seed + 1)
+    p1, p2 = s["p1"].copy(), s["p2"].copy()
+    bad = rng.random(n) < outliers
+    p2[bad] = np.stack([rng.uniform(0, 1280, bad.sum()), rng.uniform(0, 720, bad.sum())], 1)
+    return p1, p2.astype(np.float32), ~bad, s
+
+
+def same_up_to_rounding(E, oE):
+    np.testing.assert_allclose(E, oE, rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("n,seed,outliers,thresh", [(3000, 1, 0.3, 0.5), (5000, 2, 0.1, 1.0), (400, 3, 0.5, 1.0),
+                                                    (40, 4, 0.0, 0.5), (6, 5, 0.0, 1.0), (1500, 6, 0.7, 2.0)])
+def test_ransac_matches_oracle(ctx, oracle, n, seed, outliers, thresh):
+    p1, p2, truth, s = two_view(n, seed, outliers)
+    E, mask = ctx.find_essential(p1, p2, s["K"], 0, 0.99, thresh)
+    oE, omask, iters = oracle.find_essential(p1, p2, s["K"], 0, 0.99, thresh)
+    assert len(E) == len(oE) == 1
+    np.testing.assert_array_equal(mask, omask)
+    same_up_to_rounding(E, oE)
+    if outliers <= 0.5 and n >= 400:
+        kept = mask.astype(bool)
+        assert truth[kept].mean() > 0.95 and kept.sum() > 0.3 * truth.sum()
+
+
+@pytest.mark.parametrize("n,seed", [(300, 11), (12, 12), (6, 13), (2000, 14)])
+def test_lmeds_matches_oracle(ctx, oracle, n, seed):
+    p1, p2, truth, s = two_view(n, seed, 0.2)
+    E, mask = ctx.find_essential(p1, p2, s["K"], 1, 0.99, 1.0)
+    oE, omask, iters = oracle.find_essential(p1, p2, s["K"], 1, 0.99, 1.0)
+    assert len(E) == len(oE)
+    np.testing.assert_array_equal(mask, omask)
+    same_up_to_rounding(E, oE)
+
+
+@pytest.mark.parametrize("n", [0, 3, 4, 5])
+def test_minimal_and_too_small_sets(ctx, oracle, n):
+    """Fewer than five points: nothing.  Exactly five: every solution of the direct solve,
+    stacked, and a mask of ones (the reference rejects the 3k x 3 result)."""
+    p1, p2, _, s = two_view(20, 21, 0.0, sigma=0.0)
+    E, mask = ctx.find_essential(p1[:n], p2[:n], s["K"], 0, 0.99, 1.0)
+    if n < 5:
+        assert len(E) == 0 and (mask == 0).all()
+        return
+    oE, omask, _ = oracle.find_essential(p1[:n], p2[:n], s["K"], 0, 0.99, 1.0)
+    assert len(E) == len(oE) >= 1 and (mask == 1).all()
+    same_up_to_rounding(E, oE)
+
+
+def test_five_point_defining_properties(ctx):
+    """Every matrix of a direct solve satisfies the epipolar constraint on its five points,
+    is singular and has two equal singular values (needs no oracle)."""
+    p1, p2, _, s = two_view(5, 31, 0.0, sigma=0.0)
+    E, _ = ctx.find_essential(p1, p2, s["K"], 0, 0.99, 1.0)
+    Kinv = np.linalg.inv(s["K"])
+    h1 = np.c_[p1.astype(np.float64), np.ones(5)] @ Kinv.T
+    h2 = np.c_[p2.astype(np.float64), np.ones(5)] @ Kinv.T
+    assert len(E) >= 1
+    for Ek in E:
+        assert np.abs(np.einsum("ni,ij,nj->n", h2, Ek, h1)).max() < 1e-12
+        sv = np.linalg.svd(Ek, compute_uv=False)
+        assert sv[2] < 1e-9 and abs(sv[0] - sv[1]) < 1e-7
+
+
+def test_batched_device_problems(ctx, oracle):
+    import torch
+
+    sets = [two_view(900, 41, 0.3), two_view(700, 42, 0.1), two_view(5, 43, 0.0), two_view(3, 44, 0.0),
+            two_view(64, 45, 0.2)]
+    stride, P = 900, len(sets)
+    K = sets[0][3]["K"]
+    pts1 = np.zeros((P, stride, 2), np.float32)
+    pts2 = np.zeros((P, stride, 2), np.float32)
+    counts = np.array([len(s[0]) for s in sets], np.int32)
+    for k, (a, b, _, _) in enumerate(sets):
+        pts1[k, : len(a)], pts2[k, : len(b)] = a, b
+    d1, d2 = torch.from_numpy(pts1).cuda(), torch.from_numpy(pts2).cuda()
+    dc = torch.from_numpy(counts).cuda()
+    dE = torch.zeros((P, 10, 9), dtype=torch.float64, device="cuda")
+    dm = torch.full((P, stride), 9, dtype=torch.uint8, device="cuda")
+    df = torch.zeros(P, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.find_essential_dev(d1, d2, stride, dc, 0, P, K, 0, 0.99, 1.0, 1000, dE, dm, df)
+    ctx.synchronize()
+    masks, founds, Es = dm.cpu().numpy(), df.cpu().numpy(), dE.cpu().numpy()
+    for k, (a, b, _, _) in enumerate(sets):
+        n = len(a)
+        oE, omask, _ = oracle.find_essential(a, b, K, 0, 0.99, 1.0)
+        assert founds[k] == len(oE)
+        if n >= 5:
+            np.testing.assert_array_equal(masks[k, :n], omask)
+            same_up_to_rounding(Es[k, : len(oE)].reshape(-1, 3, 3), oE)
+        assert (masks[k, n:] == 9).all()
