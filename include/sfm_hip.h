@@ -303,6 +303,36 @@ int sfm_find_essential_dev(sfm_ctx* ctx, const float* d_pts1, const float* d_pts
                            int32_t* d_found);
 size_t sfm_find_essential_workspace(int n_problems, size_t problem_stride, int max_iters);
 
+/* cv::recoverPose(E, prevPts, currPts, cameraK, R, t, mask) of Tracking::findCameraPose,
+ * Source Files/tracking.cpp:110 (distanceThresh 50, OpenCV's default).  E: 9 doubles; pts:
+ * n (x, y) float pairs in pixels; mask_io: n bytes, on input the inlier mask of
+ * sfm_find_essential (all ones for "no mask"), on output cleared where the chosen pose fails
+ * the cheirality test; *good receives the number of points that pass (the function's return
+ * value in OpenCV).  R: 9 doubles row-major, t: 3 doubles. */
+int sfm_recover_pose(sfm_ctx* ctx, const double* E, const float* pts1, const float* pts2, int n, const double* K,
+                     double* R, double* t, uint8_t* mask_io, int* good);
+
+/* Many device-resident point sets per call.  d_E: problem p's matrix at d_E + p * E_stride
+ * doubles (E_stride 90 chains after sfm_find_essential_dev); d_found (optional): a problem is
+ * only processed when its entry is exactly 1; max_first_residual > 0 adds the reference's
+ * test | p1^T K^-T E K^-1 p0 | <= limit on the first correspondence (Source Files/
+ * tracking.cpp:99-107, 1e-3 there).  Problems that are skipped get d_good = 0. */
+int sfm_recover_pose_dev(sfm_ctx* ctx, const double* d_E, size_t E_stride, const int32_t* d_found,
+                         const float* d_pts1, const float* d_pts2, size_t problem_stride, const int32_t* d_counts,
+                         int count_uniform, int n_problems, const double* K, double distance_thresh,
+                         double max_first_residual, double* d_R, double* d_t, uint8_t* d_mask_io, int32_t* d_good);
+size_t sfm_recover_pose_workspace(int n_problems, size_t problem_stride);
+
+/* Tracking::findCameraPose, Source Files/tracking.cpp:91-113, for many device-resident point
+ * sets without a host round trip: sfm_find_essential_dev, the 3x3 and residual checks, then
+ * sfm_recover_pose_dev.  d_inliers[p] is numInliers (0 where the reference returns false
+ * before recoverPose); the caller compares it with minInliers.  d_E: [n_problems][10][9]. */
+int sfm_find_camera_pose_dev(sfm_ctx* ctx, const float* d_pts1, const float* d_pts2, size_t problem_stride,
+                             const int32_t* d_counts, int count_uniform, int n_problems, const double* K, int method,
+                             double prob, double threshold, double* d_E, double* d_R, double* d_t, uint8_t* d_mask,
+                             int32_t* d_found, int32_t* d_inliers);
+size_t sfm_find_camera_pose_workspace(int n_problems, size_t problem_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,5 +11,6 @@ call raises.
 from . import capi  # noqa: F401
 from .feature_processing import DescriptorMatcher, FeatureDetector, OptFlow  # noqa: F401
 from .reconstruction import CameraParameters, Reconstruction  # noqa: F401
+from .tracking import RecoveryPose, Tracking  # noqa: F401
 
-__all__ = ["capi", "DescriptorMatcher", "FeatureDetector", "OptFlow", "Reconstruction", "CameraParameters"]
+__all__ = ["capi", "DescriptorMatcher", "FeatureDetector", "OptFlow", "Reconstruction", "CameraParameters", "RecoveryPose", "Tracking"]

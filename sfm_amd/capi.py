@@ -17,6 +17,7 @@ except Exception:  # pragma: no cover
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsfm_hip.so")
 
+POSE_RANSAC, POSE_LMEDS = 0, 1  # SFM_POSE_*
 NORM_HAMMING, NORM_L2, NORM_L2SQR = 0, 1, 2
 TERM_COUNT, TERM_EPS = 1, 2
 
@@ -39,6 +40,8 @@ EXPORTS = [
     "sfm_good_features", "sfm_good_features_dev", "sfm_good_features_workspace",
     "sfm_min_eigen_val_dev",
     "sfm_find_essential", "sfm_find_essential_dev", "sfm_find_essential_workspace",
+    "sfm_recover_pose", "sfm_recover_pose_dev", "sfm_recover_pose_workspace",
+    "sfm_find_camera_pose_dev", "sfm_find_camera_pose_workspace",
 ]
 
 
@@ -65,7 +68,8 @@ def lib():
         l.sfm_ctx_destroy.restype = None
         l.sfm_ctx_destroy.argtypes = [C.c_void_p]
         for name in ("sfm_match_pairs_workspace", "sfm_pyrlk_workspace", "sfm_fundamental_workspace",
-                     "sfm_epipolar_filter_pairs_workspace", "sfm_good_features_workspace", "sfm_find_essential_workspace"):
+                     "sfm_epipolar_filter_pairs_workspace", "sfm_good_features_workspace", "sfm_find_essential_workspace", "sfm_recover_pose_workspace",
+                     "sfm_find_camera_pose_workspace"):
             if hasattr(l, name):
                 getattr(l, name).restype = C.c_size_t
         _lib = l
@@ -357,6 +361,33 @@ class Context:
     def find_essential_workspace(n_problems, problem_stride, max_iters=1000):
         return int(lib().sfm_find_essential_workspace(C.c_int(n_problems), C.c_size_t(problem_stride),
                                                       C.c_int(max_iters)))
+
+    def recover_pose(self, E, pts1, pts2, K, mask=None):
+        """cv::recoverPose(E, pts1, pts2, K, R, t, mask): returns (count, R [3,3], t [3], mask)."""
+        E = np.ascontiguousarray(E, dtype=np.float64).reshape(3, 3)
+        p1 = np.ascontiguousarray(pts1, dtype=np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(pts2, dtype=np.float32).reshape(-1, 2)
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+        n = p1.shape[0]
+        m = np.ones(max(n, 1), np.uint8) if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).copy()
+        R, t = np.zeros(9), np.zeros(3)
+        good = C.c_int(0)
+        self.check(lib().sfm_recover_pose(self._h, _ptr(E), _ptr(p1), _ptr(p2), C.c_int(n), _ptr(K), _ptr(R),
+                                          _ptr(t), _ptr(m), C.byref(good)))
+        return good.value, R.reshape(3, 3), t, m[:n]
+
+    def find_camera_pose_dev(self, d_pts1, d_pts2, problem_stride, d_counts, count_uniform, n_problems, K,
+                             method, prob, threshold, d_E, d_R, d_t, d_mask, d_found, d_inliers):
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(3, 3)
+        self.check(lib().sfm_find_camera_pose_dev(
+            self._h, _ptr(d_pts1), _ptr(d_pts2), C.c_size_t(problem_stride), _ptr(d_counts),
+            C.c_int(count_uniform), C.c_int(n_problems), _ptr(K), C.c_int(method), C.c_double(prob),
+            C.c_double(threshold), _ptr(d_E), _ptr(d_R), _ptr(d_t), _ptr(d_mask), _ptr(d_found),
+            _ptr(d_inliers)))
+
+    @staticmethod
+    def find_camera_pose_workspace(n_problems, problem_stride):
+        return int(lib().sfm_find_camera_pose_workspace(C.c_int(n_problems), C.c_size_t(problem_stride)))
 
     def good_features(self, img, max_corners, quality, min_distance):
         """cv::goodFeaturesToTrack(img, maxCorners, qualityLevel, minDistance): float32 [n, 2],

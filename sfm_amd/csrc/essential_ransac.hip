@@ -895,4 +895,24 @@ int sfm_find_essential(sfm_ctx* ctx, const float* pts1, const float* pts2, int n
     return SFM_OK;
 }
 
+size_t sfm_find_camera_pose_workspace(int n_problems, size_t problem_stride) {
+    return std::max(sfm_find_essential_workspace(n_problems, problem_stride, 1000),
+                    sfm_recover_pose_workspace(n_problems, problem_stride));
+}
+
+int sfm_find_camera_pose_dev(sfm_ctx* ctx, const float* d_pts1, const float* d_pts2, size_t problem_stride,
+                             const int32_t* d_counts, int count_uniform, int n_problems, const double* K, int method,
+                             double prob, double threshold, double* d_E, double* d_R, double* d_t, uint8_t* d_mask,
+                             int32_t* d_found, int32_t* d_inliers) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    // both stages carve the same workspace from its start; reserving the larger one first
+    // keeps the second call from reallocating it under the first one's kernels
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, sfm_find_camera_pose_workspace(n_problems, problem_stride), &ws));
+    SFM_RETURN_IF(sfm_find_essential_dev(ctx, d_pts1, d_pts2, problem_stride, d_counts, count_uniform, n_problems, K,
+                                         method, prob, threshold, 1000, d_E, d_mask, d_found));
+    return sfm_recover_pose_dev(ctx, d_E, (size_t)kMaxModels * 9, d_found, d_pts1, d_pts2, problem_stride, d_counts,
+                                count_uniform, n_problems, K, 50.0, 1e-3, d_R, d_t, d_mask, d_inliers);
+}
+
 }  // extern "C"

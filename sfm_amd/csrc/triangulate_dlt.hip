@@ -547,7 +547,333 @@ void set_cameras(TriArgs& a, const double* K, const double* prev_pose, const dou
 
 int run_triangulation(sfm_ctx* ctx, TriArgs& a);
 
+// ---- cv::recoverPose -------------------------------------------------------------------------
+// (Tracking::findCameraPose, Source Files/tracking.cpp:110): decomposeEssentialMat gives two
+// rotations and a translation direction; each of the four (R, +-t) is tested by triangulating
+// every correspondence (the 4x4 system and Jacobi SVD of cv::triangulatePoints, on points
+// normalised by K, cameras [I|0] and [R|t]) and counting the points in front of both cameras
+// and nearer than distanceThresh; the candidate with the most such points wins.
+
+struct PoseArgs {
+    const double* E;        // [problem][E_stride] doubles, the first nine used
+    size_t E_stride;
+    const int32_t* found;   // per problem: exactly 1 to proceed (nullptr: all proceed)
+    const float2* pix1;
+    const float2* pix2;
+    size_t stride;
+    const int32_t* counts;
+    int count_uniform;
+    int n_problems;
+    double fx, fy, cx, cy, dist;
+    double max_first_residual;  // > 0: the reference's check of the first correspondence
+    double* cand;           // [problem][4][12]: [R | t] row-major
+    int32_t* ok;            // [problem]
+    int32_t* good;          // [problem][4]
+    uint8_t* bits;          // [problem][stride]: bit k set = passes candidate k
+    double* R;              // [problem][9]
+    double* t;              // [problem][3]
+    uint8_t* mask;          // [problem][stride] in/out
+    int32_t* n_good;        // [problem]
+};
+
+__device__ __forceinline__ int pose_count(const PoseArgs& a, int p) {
+    const int c = a.counts ? a.counts[p] : a.count_uniform;
+    return c < 0 ? 0 : (c > (int)a.stride ? (int)a.stride : c);
+}
+
+__device__ double det3(const double* m) {
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+// One-sided Jacobi SVD of a 3x3 matrix (row-major a): a = u diag(w) v^T, w descending.
+__device__ void svd3(const double* a, double* u, double* w, double* v) {
+    double at[3][3], vt[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) at[i][j] = a[3 * j + i];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool changed = false;
+        for (int i = 0; i < 2; ++i)
+            for (int j = i + 1; j < 3; ++j) {
+                double p = 0, qa = 0, qb = 0;
+                for (int k = 0; k < 3; ++k) p += at[i][k] * at[j][k], qa += at[i][k] * at[i][k], qb += at[j][k] * at[j][k];
+                if (fabs(p) <= DBL_EPSILON * sqrt(qa * qb)) continue;
+                p *= 2;
+                const double beta = qa - qb, gamma = hypot(p, beta);
+                double c, s;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double t0 = c * at[i][k] + s * at[j][k], t1 = -s * at[i][k] + c * at[j][k];
+                    at[i][k] = t0;
+                    at[j][k] = t1;
+                    const double v0 = c * vt[i][k] + s * vt[j][k], v1 = -s * vt[i][k] + c * vt[j][k];
+                    vt[i][k] = v0;
+                    vt[j][k] = v1;
+                }
+                changed = true;
+            }
+        if (!changed) break;
+    }
+    double sv[3];
+    for (int i = 0; i < 3; ++i) sv[i] = sqrt(at[i][0] * at[i][0] + at[i][1] * at[i][1] + at[i][2] * at[i][2]);
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 2; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (sv[order[j]] > sv[order[i]]) {
+                const int t = order[i];
+                order[i] = order[j];
+                order[j] = t;
+            }
+    for (int c = 0; c < 3; ++c) {
+        const int i = order[c];
+        w[c] = sv[i];
+        for (int k = 0; k < 3; ++k) {
+            v[3 * k + c] = vt[i][k];
+            u[3 * k + c] = sv[i] > 0 ? at[i][k] / sv[i] : 0;
+        }
+    }
+    // a rank-2 matrix leaves the last column of u undetermined: complete it
+    if (!(w[2] > DBL_EPSILON * w[0])) {
+        u[2] = u[3] * u[7] - u[6] * u[4];
+        u[5] = u[6] * u[1] - u[0] * u[7];
+        u[8] = u[0] * u[4] - u[3] * u[1];
+    }
+}
+
+// cv::decomposeEssentialMat and the four candidates; the reference's residual test.
+__global__ void pose_decompose_kernel(PoseArgs a) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n_problems) return;
+    for (int k = 0; k < 4; ++k) a.good[4 * p + k] = 0;
+    const int count = pose_count(a, p);
+    int ok = (!a.found || a.found[p] == 1) && count > 0;
+    const double* E = a.E + (size_t)p * a.E_stride;
+    if (ok && a.max_first_residual > 0) {
+        // | p1^T K^-T E K^-1 p0 | of the first correspondence (Source Files/tracking.cpp:99-107)
+        const float2 u0 = a.pix1[(size_t)p * a.stride], u1 = a.pix2[(size_t)p * a.stride];
+        const double x0[3] = {((double)u0.x - a.cx) / a.fx, ((double)u0.y - a.cy) / a.fy, 1.0};
+        const double x1[3] = {((double)u1.x - a.cx) / a.fx, ((double)u1.y - a.cy) / a.fy, 1.0};
+        double s = 0;
+        for (int r = 0; r < 3; ++r) s += x1[r] * (E[3 * r] * x0[0] + E[3 * r + 1] * x0[1] + E[3 * r + 2] * x0[2]);
+        ok = !(fabs(s) > a.max_first_residual);
+    }
+    a.ok[p] = ok;
+    if (!ok) return;
+    double u[9], w[3], v[9];
+    svd3(E, u, w, v);
+    if (det3(u) < 0)
+        for (int i = 0; i < 9; ++i) u[i] = -u[i];
+    if (det3(v) < 0)
+        for (int i = 0; i < 9; ++i) v[i] = -v[i];
+    double uw[9], uwt[9];  // U W and U W^T, W = [0 1 0; -1 0 0; 0 0 1]
+    for (int r = 0; r < 3; ++r) {
+        uw[3 * r + 0] = -u[3 * r + 1];
+        uw[3 * r + 1] = u[3 * r + 0];
+        uw[3 * r + 2] = u[3 * r + 2];
+        uwt[3 * r + 0] = u[3 * r + 1];
+        uwt[3 * r + 1] = -u[3 * r + 0];
+        uwt[3 * r + 2] = u[3 * r + 2];
+    }
+    double* cand = a.cand + (size_t)p * 48;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) {
+            double s1 = 0, s2 = 0;
+            for (int k = 0; k < 3; ++k) s1 += uw[3 * r + k] * v[3 * c + k], s2 += uwt[3 * r + k] * v[3 * c + k];
+            cand[0 * 12 + 4 * r + c] = cand[2 * 12 + 4 * r + c] = s1;  // R1 with t, R1 with -t
+            cand[1 * 12 + 4 * r + c] = cand[3 * 12 + 4 * r + c] = s2;  // R2 with t, R2 with -t
+        }
+        const double tr = u[3 * r + 2];
+        cand[0 * 12 + 4 * r + 3] = cand[1 * 12 + 4 * r + 3] = tr;
+        cand[2 * 12 + 4 * r + 3] = cand[3 * 12 + 4 * r + 3] = -tr;
+    }
+}
+
+// One lane per correspondence: the four cheirality tests.
+__global__ __launch_bounds__(256) void pose_cheirality_kernel(PoseArgs a) {
+    __shared__ int s_good[4];
+    const int p = blockIdx.y, tid = threadIdx.x;
+    if (!a.ok[p]) return;
+    if (tid < 4) s_good[tid] = 0;
+    __syncthreads();
+    const int count = pose_count(a, p);
+    const double* cand = a.cand + (size_t)p * 48;
+    int mine[4] = {0, 0, 0, 0};
+    for (int i = blockIdx.x * blockDim.x + tid; i < count; i += gridDim.x * blockDim.x) {
+        const size_t k = (size_t)p * a.stride + i;
+        const float2 u1 = a.pix1[k], u2 = a.pix2[k];
+        const double x1 = ((double)u1.x - a.cx) / a.fx, y1 = ((double)u1.y - a.cy) / a.fy;
+        const double x2 = ((double)u2.x - a.cx) / a.fx, y2 = ((double)u2.y - a.cy) / a.fy;
+        const bool counted = a.mask[k] != 0;
+        unsigned bits = 0;
+        for (int c = 0; c < 4; ++c) {
+            const double* P = cand + 12 * c;
+            double At[4][4], q[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double p0_row2 = j == 2 ? 1.0 : 0.0;  // [I | 0]
+                At[j][0] = x1 * p0_row2 - (j == 0 ? 1.0 : 0.0);
+                At[j][1] = y1 * p0_row2 - (j == 1 ? 1.0 : 0.0);
+                At[j][2] = x2 * P[8 + j] - P[j];
+                At[j][3] = y2 * P[8 + j] - P[4 + j];
+            }
+            null_vector_jacobi(At, q);
+            bool pass = q[2] * q[3] > 0;
+            const double X = q[0] / q[3], Y = q[1] / q[3], Z = q[2] / q[3];
+            pass = pass && Z < a.dist;
+            const double z2 = P[8] * X + P[9] * Y + P[10] * Z + P[11] * 1.0;
+            pass = pass && z2 > 0 && z2 < a.dist;
+            bits |= pass ? 1u << c : 0u;
+            mine[c] += pass && counted;
+        }
+        a.bits[k] = (uint8_t)bits;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int v = mine[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0 && v) atomicAdd(&s_good[c], v);
+    }
+    __syncthreads();
+    if (tid < 4 && s_good[tid]) atomicAdd(a.good + 4 * p + tid, s_good[tid]);
+}
+
+// The winner (first of the best, in OpenCV's order), its R and t, the mask.
+__global__ __launch_bounds__(256) void pose_pick_kernel(PoseArgs a) {
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int count = pose_count(a, p);
+    uint8_t* mask = a.mask + (size_t)p * a.stride;
+    if (!a.ok[p]) {
+        if (tid == 0) a.n_good[p] = 0;
+        return;
+    }
+    const int g0 = a.good[4 * p], g1 = a.good[4 * p + 1], g2 = a.good[4 * p + 2], g3 = a.good[4 * p + 3];
+    int pick;
+    if (g0 >= g1 && g0 >= g2 && g0 >= g3) pick = 0;
+    else if (g1 >= g0 && g1 >= g2 && g1 >= g3) pick = 1;
+    else if (g2 >= g0 && g2 >= g1 && g2 >= g3) pick = 2;
+    else pick = 3;
+    const double* P = a.cand + (size_t)p * 48 + 12 * pick;
+    if (tid < 9) a.R[(size_t)p * 9 + tid] = P[4 * (tid / 3) + tid % 3];
+    if (tid < 3) a.t[(size_t)p * 3 + tid] = P[4 * tid + 3];
+    if (tid == 0) a.n_good[p] = a.good[4 * p + pick];
+    const uint8_t* bits = a.bits + (size_t)p * a.stride;
+    for (int i = tid; i < count; i += blockDim.x) mask[i] = ((bits[i] >> pick) & 1) ? mask[i] : 0;
+}
+
 }  // namespace
+
+extern "C" size_t sfm_recover_pose_workspace(int n_problems, size_t problem_stride) {
+    if (n_problems <= 0 || problem_stride == 0) return 0;
+    Carver c(nullptr);
+    c.take<double>((size_t)n_problems * 48);
+    c.take<int32_t>((size_t)n_problems);
+    c.take<int32_t>((size_t)n_problems * 4);
+    c.take<uint8_t>((size_t)n_problems * problem_stride);
+    return c.total();
+}
+
+extern "C" int sfm_recover_pose_dev(sfm_ctx* ctx, const double* d_E, size_t E_stride, const int32_t* d_found,
+                                    const float* d_pts1, const float* d_pts2, size_t problem_stride,
+                                    const int32_t* d_counts, int count_uniform, int n_problems, const double* K,
+                                    double distance_thresh, double max_first_residual, double* d_R, double* d_t,
+                                    uint8_t* d_mask_io, int32_t* d_good) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (n_problems < 0) return set_error(ctx, SFM_E_INVALID, "negative problem count");
+    if (n_problems == 0) return SFM_OK;
+    if (!d_E || !d_pts1 || !d_pts2 || !K || !d_R || !d_t || !d_mask_io || !d_good)
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (E_stride < 9 || problem_stride == 0 || problem_stride > 0x7fffffff ||
+        (!d_counts && (count_uniform < 0 || (size_t)count_uniform > problem_stride)))
+        return set_error(ctx, SFM_E_INVALID, "bad stride or point count");
+    if (!(K[0] != 0) || !(K[4] != 0)) return set_error(ctx, SFM_E_INVALID, "camera matrix without focal lengths");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // the essential-matrix stage may have left its result in the workspace's front: work behind it
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, sfm_recover_pose_workspace(n_problems, problem_stride), &ws));
+    Carver c(ws);
+    PoseArgs a{};
+    a.E = d_E;
+    a.E_stride = E_stride;
+    a.found = d_found;
+    a.pix1 = reinterpret_cast<const float2*>(d_pts1);
+    a.pix2 = reinterpret_cast<const float2*>(d_pts2);
+    a.stride = problem_stride;
+    a.counts = d_counts;
+    a.count_uniform = count_uniform;
+    a.n_problems = n_problems;
+    a.fx = K[0];
+    a.fy = K[4];
+    a.cx = K[2];
+    a.cy = K[5];
+    a.dist = distance_thresh;
+    a.max_first_residual = max_first_residual;
+    a.cand = c.take<double>((size_t)n_problems * 48);
+    a.ok = c.take<int32_t>((size_t)n_problems);
+    a.good = c.take<int32_t>((size_t)n_problems * 4);
+    a.bits = c.take<uint8_t>((size_t)n_problems * problem_stride);
+    a.R = d_R;
+    a.t = d_t;
+    a.mask = d_mask_io;
+    a.n_good = d_good;
+    KernelTimer timer(ctx, KID_POSE);
+    hipLaunchKernelGGL(pose_decompose_kernel, dim3((n_problems + 63) / 64), dim3(64), 0, ctx->stream, a);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(pose_cheirality_kernel, dim3((unsigned)std::min<size_t>((problem_stride + 255) / 256, 256), n_problems),
+                       dim3(256), 0, ctx->stream, a);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(pose_pick_kernel, dim3(n_problems), dim3(256), 0, ctx->stream, a);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+extern "C" int sfm_recover_pose(sfm_ctx* ctx, const double* E, const float* pts1, const float* pts2, int n,
+                                const double* K, double* R, double* t, uint8_t* mask_io, int* good) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (good) *good = 0;
+    if (n < 0) return set_error(ctx, SFM_E_INVALID, "negative point count");
+    if (!E || !K || !R || !t || (n > 0 && (!pts1 || !pts2 || !mask_io)))
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (n == 0) return SFM_OK;
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    Carver sz(nullptr);
+    sz.take<float>(2 * (size_t)n);
+    sz.take<float>(2 * (size_t)n);
+    sz.take<double>(9 + 9 + 3);
+    sz.take<uint8_t>((size_t)n);
+    sz.take<int32_t>(4);
+    void* st;
+    SFM_RETURN_IF(staging(ctx, sz.total(), &st));
+    Carver c(st);
+    float* d1 = c.take<float>(2 * (size_t)n);
+    float* d2 = c.take<float>(2 * (size_t)n);
+    double* dE = c.take<double>(9 + 9 + 3);
+    uint8_t* dm = c.take<uint8_t>((size_t)n);
+    int32_t* dg = c.take<int32_t>(4);
+    hipStream_t s = ctx->stream;
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(d1, pts1, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(d2, pts2, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(dE, E, sizeof(double) * 9, hipMemcpyHostToDevice, s));
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(dm, mask_io, (size_t)n, hipMemcpyHostToDevice, s));
+    SFM_RETURN_IF(sfm_recover_pose_dev(ctx, dE, 9, nullptr, d1, d2, (size_t)n, nullptr, n, 1, K, 50.0, 0.0, dE + 9,
+                                       dE + 18, dm, dg));
+    double h[12];
+    int32_t h_good = 0;
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(h, dE + 9, sizeof(h), hipMemcpyDeviceToHost, s));
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(mask_io, dm, (size_t)n, hipMemcpyDeviceToHost, s));
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(&h_good, dg, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SFM_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    for (int i = 0; i < 9; ++i) R[i] = h[i];
+    for (int i = 0; i < 3; ++i) t[i] = h[9 + i];
+    if (good) *good = h_good;
+    return SFM_OK;
+}
 
 int sfm_triangulate_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
                         const double* curr_pose, const double* R, const double* t,

@@ -119,3 +119,79 @@ def test_batched_device_problems(ctx, oracle):
             np.testing.assert_array_equal(masks[k, :n], omask)
             same_up_to_rounding(Es[k, : len(oE)].reshape(-1, 3, 3), oE)
         assert (masks[k, n:] == 9).all()
+
+
+@pytest.mark.parametrize("n,seed,outliers", [(3000, 51, 0.3), (500, 52, 0.1), (60, 53, 0.0)])
+def test_recover_pose_matches_oracle(ctx, oracle, n, seed, outliers):
+    p1, p2, truth, s = two_view(n, seed, outliers)
+    oE, omask, _ = oracle.find_essential(p1, p2, s["K"], 0, 0.99, 1.0)
+    cnt, R, t, mask = ctx.recover_pose(oE[0], p1, p2, s["K"], omask)
+    ocnt, oR, ot, omask2 = oracle.recover_pose(oE[0], p1, p2, s["K"], omask)
+    assert cnt == ocnt and cnt > 0.5 * omask.sum()
+    np.testing.assert_array_equal(mask, omask2)
+    np.testing.assert_allclose(R, oR, atol=1e-10)
+    np.testing.assert_allclose(t, ot, atol=1e-10)
+    # and it is, roughly (a minimal-sample model on noisy points), the pose the data were
+    # generated with, translation up to scale
+    np.testing.assert_allclose(R, s["R"], atol=6e-2)
+    assert t @ (s["t"] / np.linalg.norm(s["t"])) > 0.98
+    # without a mask every point is counted
+    cnt_all, _, _, mask_all = ctx.recover_pose(oE[0], p1, p2, s["K"])
+    ocnt_all, _, _, omask_all = oracle.recover_pose(oE[0], p1, p2, s["K"])
+    assert cnt_all == ocnt_all and np.array_equal(mask_all, omask_all)
+
+
+def test_find_camera_pose_wrapper(ctx, oracle):
+    """Tracking::findCameraPose end to end against the same steps done with the oracle."""
+    from sfm_amd import RecoveryPose, Tracking
+
+    p1, p2, truth, s = two_view(2500, 61, 0.25)
+    rp = RecoveryPose("RANSAC", 0.99, 0.5, 10)
+    ok, n_in = Tracking.findCameraPose(rp, p1, p2, s["K"], rp.minInliers, ctx=ctx)
+    oE, omask, _ = oracle.find_essential(p1, p2, s["K"], 0, 0.99, 0.5)
+    assert len(oE) == 1
+    want_ok = oracle.essential_residual(oE[0], p1[0], p2[0], s["K"]) <= 1e-3
+    if want_ok:
+        ocnt, oR, ot, omask2 = oracle.recover_pose(oE[0], p1, p2, s["K"], omask)
+        assert ok == (ocnt > 10) and n_in == ocnt
+        np.testing.assert_array_equal(rp.mask, omask2)
+        np.testing.assert_allclose(rp.R, oR, atol=1e-8)
+    else:
+        assert not ok
+    # too few points: false, as the reference's first line
+    assert Tracking.findCameraPose(rp, p1[:5], p2[:5], s["K"], 10, ctx=ctx) == (False, 0)
+
+
+def test_find_camera_pose_batched_on_device(ctx, oracle):
+    import torch
+
+    sets = [two_view(1200, 71, 0.3), two_view(800, 72, 0.1), two_view(5, 73, 0.0), two_view(300, 74, 0.2)]
+    stride, P = 1200, len(sets)
+    K = sets[0][3]["K"]
+    pts1 = np.zeros((P, stride, 2), np.float32)
+    pts2 = np.zeros((P, stride, 2), np.float32)
+    counts = np.array([len(s[0]) for s in sets], np.int32)
+    for k, (a, b, _, _) in enumerate(sets):
+        pts1[k, : len(a)], pts2[k, : len(b)] = a, b
+    d1, d2 = torch.from_numpy(pts1).cuda(), torch.from_numpy(pts2).cuda()
+    dc = torch.from_numpy(counts).cuda()
+    dE = torch.zeros((P, 10, 9), dtype=torch.float64, device="cuda")
+    dR = torch.zeros((P, 9), dtype=torch.float64, device="cuda")
+    dt = torch.zeros((P, 3), dtype=torch.float64, device="cuda")
+    dm = torch.zeros((P, stride), dtype=torch.uint8, device="cuda")
+    df = torch.zeros(P, dtype=torch.int32, device="cuda")
+    di = torch.zeros(P, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.find_camera_pose_dev(d1, d2, stride, dc, 0, P, K, 0, 0.99, 0.5, dE, dR, dt, dm, df, di)
+    ctx.synchronize()
+    inl, masks, Rs = di.cpu().numpy(), dm.cpu().numpy(), dR.cpu().numpy()
+    for k, (a, b, _, _) in enumerate(sets):
+        n = len(a)
+        oE, omask, _ = oracle.find_essential(a, b, K, 0, 0.99, 0.5)
+        if len(oE) != 1 or oracle.essential_residual(oE[0], a[0], b[0], K) > 1e-3:
+            assert inl[k] == 0
+            continue
+        ocnt, oR, ot, omask2 = oracle.recover_pose(oE[0], a, b, K, omask)
+        assert inl[k] == ocnt
+        np.testing.assert_array_equal(masks[k, :n], omask2)
+        np.testing.assert_allclose(Rs[k].reshape(3, 3), oR, atol=1e-8)
