@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="framepair", choices=["framepair", "c3", "c4", "c5", "f1", "f3"])
+    ap.add_argument("--workload", default="framepair", choices=["framepair", "c3", "c4", "c5", "f1", "f2", "f3"])
     ap.add_argument("--pairs", type=int, default=32, help="frame pairs per rank and step")
     ap.add_argument("--frames", type=int, default=512, help="c5: frames in the window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -591,6 +591,95 @@ def run_f1(args, rank, world, local):
     return out
 
 
+# --------------------------------------------------------------------------- f2 relative pose
+def run_f2(args, rank, world, local):
+    """Tracking::findCameraPose (tracking.cpp:91-113) for P device-resident sets of tracked
+    points per step: findEssentialMat (five-point RANSAC, prob 0.99, threshold 0.5 px: the
+    reference's defaults), the residual check, recoverPose."""
+    import torch
+
+    from sfm_amd import capi, synth
+
+    dev = torch.device("cuda", local)
+    P, N = args.pairs, LK_POINTS
+    ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(4242 + rank)
+    pts1 = np.zeros((P, N, 2), np.float32)
+    pts2 = np.zeros((P, N, 2), np.float32)
+    K = None
+    for p in range(P):
+        s = synth.triangulation_set(N, seed=100 + p + 1000 * rank, sigma=0.2, outliers=0.0)
+        K = s["K"]
+        b = s["p2"].copy()
+        wrong = rng.random(N) < 0.2      # mistracked points
+        b[wrong] = np.stack([rng.uniform(0, LK_W, wrong.sum()), rng.uniform(0, LK_H, wrong.sum())], 1)
+        pts1[p], pts2[p] = s["p1"], b
+    d1, d2 = torch.from_numpy(pts1).to(dev), torch.from_numpy(pts2).to(dev)
+    dE = torch.zeros((P, 10, 9), dtype=torch.float64, device=dev)
+    dR = torch.zeros((P, 9), dtype=torch.float64, device=dev)
+    dt_ = torch.zeros((P, 3), dtype=torch.float64, device=dev)
+    dm = torch.zeros((P, N), dtype=torch.uint8, device=dev)
+    df = torch.zeros(P, dtype=torch.int32, device=dev)
+    di = torch.zeros(P, dtype=torch.int32, device=dev)
+    ctx.reserve(capi.Context.find_camera_pose_workspace(P, N))
+
+    def step():
+        ctx.find_camera_pose_dev(d1, d2, N, None, N, P, K, 0, 0.99, 0.5, dE, dR, dt_, dm, df, di)
+
+    dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, ctx)
+    inl = di.cpu().numpy()
+    out = {
+        "metric": "relative poses/sec (findEssentialMat five-point RANSAC + recoverPose per frame pair)",
+        "value": round(world * P * args.steps / dt, 1), "unit": "poses/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"f2: findCameraPose for {P} frame pairs/rank/step, {N} tracked points each "
+                               f"(20 % mistracked, 0.2 px noise), RANSAC 0.99 / 0.5 px / 1000"},
+        "ms_per_frame_pair": round(1e3 * dt / args.steps / P, 4),
+        "kernels": {k: kernel_line(prof, k) for k in sorted(prof)},
+        "check": {"mean_inliers": float(inl.mean()), "poses_found": int((inl > 10).sum())},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle
+
+        t0 = time.perf_counter()
+        reps, same, iters = 0, True, 0
+        while True:
+            p = reps % P
+            E, mask, it = pyoracle.find_essential(pts1[p], pts2[p], K, 0, 0.99, 0.5)
+            cnt = 0
+            if len(E) == 1 and pyoracle.essential_residual(E[0], pts1[p, 0], pts2[p, 0], K) <= 1e-3:
+                cnt, _, _, _ = pyoracle.recover_pose(E[0], pts1[p], pts2[p], K, mask)
+            if reps < P:
+                same = same and cnt == int(inl[p])
+                iters += it
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > 10.0 and reps >= P:
+                break
+        out["cpu_baseline"] = {"value": round(reps / el, 2), "unit": "poses/s", "cores": 1, "kind": "port",
+                               "sample": f"{reps} of the same point sets in {el:.1f} s, one thread, restatement "
+                                         f"not OpenCV; mean RANSAC iterations run {iters / P:.1f}",
+                               "ms_per_frame_pair": round(1e3 * el / reps, 3)}
+        out["check"]["identical_inlier_counts"] = bool(same)
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        # the Sampson tests the sequential loop makes: iterations x points, at least one model each
+        ms, cnt_l = prof.get("em_score_kernel", (0.0, 0))
+        if cnt_l:
+            evals = float(iters) * N
+            per_step_s = ms / args.steps * 1e-3
+            ach = evals * 36 / per_step_s / 1e12
+            out["roofline"] = {"kernel": "em_score_kernel", "bound": "valu_f64", "achieved": round(ach, 4),
+                               "peak": F64_VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+                               "frac": round(ach / F64_VALU_PEAK_TLANEOPS, 5),
+                               "us_per_step": round(per_step_s * 1e6, 2), "traffic": None,
+                               "algorithmic_per_launch": f"{evals:.4g} Sampson tests per step (iterations the "
+                                                         f"sequential loop runs x points, one model each; a "
+                                                         f"sample yields up to ten) x 36 fp64 lane-ops"}
+    ctx.close()
+    return out
+
+
 # --------------------------------------------------------------------------- f3 corners
 def run_f3(args, rank, world, local):
     """Shi-Tomasi corners (goodFeaturesToTrack, feature_processing.cpp:87-99) on P device-resident
@@ -670,7 +759,7 @@ def run_f3(args, rank, world, local):
 def main():
     args = parse()
     rank, world, local = dist_setup(args.gpus)
-    run = {"framepair": run_framepair, "c3": run_c3, "c4": run_c4, "c5": run_c5, "f1": run_f1, "f3": run_f3}[args.workload]
+    run = {"framepair": run_framepair, "c3": run_c3, "c4": run_c4, "c5": run_c5, "f1": run_f1, "f2": run_f2, "f3": run_f3}[args.workload]
     out = run(args, rank, world, local)
     if rank == 0:
         print(json.dumps(out))

@@ -141,11 +141,9 @@ struct Cplx {
 };
 __device__ __forceinline__ Cplx c_mul(Cplx a, Cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 
-// cv::solvePoly for degree 10 (Durand-Kerner).  coeffs lowest degree first.
-__device__ void solve_poly10(const double* coeffs, Cplx* roots) {
-    int n = 10;
-    for (; n > 1; n--)
-        if (fabs(coeffs[n]) > DBL_EPSILON) break;
+// cv::solvePoly (Durand-Kerner), generic degree: the rare case of a vanishing leading
+// coefficient.  coeffs lowest degree first.
+__device__ void solve_poly_generic(const double* coeffs, int n, Cplx* roots) {
     Cplx p = {1, 0};
     const Cplx r = {1, 1};
     for (int i = 0; i < n; i++) {
@@ -171,11 +169,64 @@ __device__ void solve_poly10(const double* coeffs, Cplx* roots) {
             const double rel = sqrt(q.re * q.re + q.im * q.im) / (1.0 + sqrt(p.re * p.re + p.im * p.im));
             max_rel = rel > max_rel ? rel : max_rel;
         }
-        // OpenCV sweeps on until a sweep changes nothing at all (in practice all 300 times);
-        // below this the corrections are rounding noise
         if (!(max_rel > 4e-16)) break;
     }
-    for (; n < 10; n++) roots[n] = roots[n - 1];
+}
+
+// cv::solvePoly for degree 10.  OpenCV sweeps until a sweep changes nothing at all (in
+// practice all 300 times); here the sweeps stop once the corrections are rounding noise.
+// The usual case (a leading coefficient that does not vanish) keeps coefficients and roots
+// in registers: every loop over them is unrolled.
+__device__ void solve_poly10(const double* coeffs_in, Cplx* roots_out) {
+    int n = 10;
+    for (; n > 1; n--)
+        if (fabs(coeffs_in[n]) > DBL_EPSILON) break;
+    if (n < 10) {
+        solve_poly_generic(coeffs_in, n, roots_out);
+        for (; n < 10; n++) roots_out[n] = roots_out[n - 1];
+        return;
+    }
+    double c[11];
+    Cplx roots[10];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) c[k] = coeffs_in[k];
+    {
+        Cplx p = {1, 0};
+        const Cplx r = {1, 1};
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            roots[i] = p;
+            p = c_mul(p, r);
+        }
+    }
+    for (int iter = 0; iter < 300; iter++) {
+        double max_rel = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const Cplx p = roots[i];
+            Cplx num = {c[10], 0}, denom = {c[10], 0};
+#pragma unroll
+            for (int j = 0; j < 10; j++) {
+                num = c_mul(num, p);
+                num.re += c[9 - j];
+                if (j != i) {
+                    const Cplx d = {p.re - roots[j].re, p.im - roots[j].im};
+                    const Cplx nd = c_mul(denom, d);
+                    const bool same = d.re == 0 && d.im == 0;
+                    denom.re = same ? denom.re : nd.re;
+                    denom.im = same ? denom.im : nd.im;
+                }
+            }
+            const double t = 1. / (denom.re * denom.re + denom.im * denom.im);
+            const Cplx q = {(num.re * denom.re + num.im * denom.im) * t, (-num.re * denom.im + num.im * denom.re) * t};
+            roots[i] = {p.re - q.re, p.im - q.im};
+            const double rel = sqrt(q.re * q.re + q.im * q.im) / (1.0 + sqrt(p.re * p.re + p.im * p.im));
+            max_rel = rel > max_rel ? rel : max_rel;
+        }
+        if (!(max_rel > 4e-16)) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; i++) roots_out[i] = roots[i];
 }
 
 // EMEstimatorCallback::runKernel for five normalised correspondences; up to ten matrices.
