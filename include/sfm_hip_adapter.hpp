@@ -27,6 +27,7 @@
 #include <cctype>
 #include <cstdint>
 #include <cstring>
+#include <cmath>
 #include <functional>
 #include <memory>
 #include <stdexcept>
@@ -51,6 +52,7 @@ inline bool mat_is_u8(const cv::Mat& m) { return m.depth() == CV_8U; }
 inline bool mat_is_f32(const cv::Mat& m) { return m.depth() == CV_32F; }
 inline int mat_channels(const cv::Mat& m) { return m.channels(); }
 inline size_t mat_step(const cv::Mat& m) { return m.step[0]; }
+inline cv::Mat mat_u8_column(int rows) { return cv::Mat(rows, 1, CV_8U); }
 [[noreturn]] inline void raise(const std::string& what) {
     CV_Error(cv::Error::StsError, what);
 }
@@ -133,6 +135,7 @@ inline bool mat_is_u8(const cvx::Mat& m) { return m.depth_ == cvx::Mat::U8; }
 inline bool mat_is_f32(const cvx::Mat& m) { return m.depth_ == cvx::Mat::F32; }
 inline int mat_channels(const cvx::Mat& m) { return m.channels_; }
 inline size_t mat_step(const cvx::Mat& m) { return m.step; }
+inline cvx::Mat mat_u8_column(int rows) { return cvx::Mat(rows, 1, cvx::Mat::U8); }
 [[noreturn]] inline void raise(const std::string& what) { throw std::runtime_error(what); }
 }  // namespace sfm_hip
 #endif
@@ -386,6 +389,66 @@ public:
                                        &count),
                      "sfm_good_features");
         corners.insert(corners.end(), found.begin(), found.begin() + count);
+    }
+};
+
+/* Header Files/tracking.h:17-32 (settings and result of the relative-pose step;
+ * drawRecoveredPose is visualisation and stays with the reference). */
+class RecoveryPose {
+public:
+    int recPoseMethod; /* SFM_POSE_RANSAC / SFM_POSE_LMEDS (cv::RANSAC / cv::LMEDS in the reference) */
+    std::string poseEstMethod;
+    const double prob, threshold;
+    const unsigned minInliers, numIter;
+    const bool useExtrinsicGuess;
+    cvx::Matx33d R;
+    cvx::Matx31d t;
+    cvx::Mat mask;
+
+    /* Source Files/tracking.cpp:3-18: "RANSAC" selects RANSAC, anything else LMedS. */
+    RecoveryPose(std::string method, const double prob_, const double threshold_, const unsigned minInliers_,
+                 std::string poseEstMethod_, const bool useExtrinsicGuess_, const unsigned numIter_)
+        : poseEstMethod(poseEstMethod_), prob(prob_), threshold(threshold_), minInliers(minInliers_),
+          numIter(numIter_), useExtrinsicGuess(useExtrinsicGuess_) {
+        std::for_each(method.begin(), method.end(), [](char& c) { c = char(::toupper(c)); });
+        recPoseMethod = method == "RANSAC" ? SFM_POSE_RANSAC : SFM_POSE_LMEDS;
+        R(0, 0) = R(1, 1) = R(2, 2) = 1.0;
+        t(0, 0) = 1.0; /* cv::Matx31d::eye() */
+    }
+};
+
+/* Header Files/tracking.h:82: the relative-pose member of Tracking. */
+class Tracking {
+public:
+    /* Source Files/tracking.cpp:91-113: findEssentialMat, the 3x3 and residual checks,
+     * recoverPose; R, t and mask are left in recPose. */
+    static bool findCameraPose(RecoveryPose& recPose, std::vector<cvx::Point2f> prevPts,
+                               std::vector<cvx::Point2f> currPts, const cvx::Matx33d& cameraK, int minInliers,
+                               int& numInliers, Handle handle = Handle::shared()) {
+        if (prevPts.size() <= 5 || currPts.size() <= 5) return false;
+        if (prevPts.size() != currPts.size()) raise("findCameraPose: point lists differ in length");
+        const int n = int(prevPts.size());
+        double E[90];
+        int n_matrices = 0;
+        recPose.mask = mat_u8_column(n);
+        handle.check(sfm_find_essential(handle.get(), reinterpret_cast<const float*>(prevPts.data()),
+                                        reinterpret_cast<const float*>(currPts.data()), n, cameraK.val,
+                                        recPose.recPoseMethod, recPose.prob, recPose.threshold, 1000, E,
+                                        recPose.mask.data, &n_matrices),
+                     "sfm_find_essential");
+        if (n_matrices != 1) return false; /* the reference's E.cols == 3 && E.rows == 3 */
+        /* | p1^T K^-T E K^-1 p0 | of the first correspondence, K upper triangular without skew */
+        const double fx = cameraK(0, 0), fy = cameraK(1, 1), cx = cameraK(0, 2), cy = cameraK(1, 2);
+        const double a[3] = {(double(prevPts[0].x) - cx) / fx, (double(prevPts[0].y) - cy) / fy, 1.0};
+        const double b[3] = {(double(currPts[0].x) - cx) / fx, (double(currPts[0].y) - cy) / fy, 1.0};
+        double err = 0;
+        for (int r = 0; r < 3; ++r) err += b[r] * (E[3 * r] * a[0] + E[3 * r + 1] * a[1] + E[3 * r + 2] * a[2]);
+        if (std::fabs(err) > 1e-03) return false;
+        handle.check(sfm_recover_pose(handle.get(), E, reinterpret_cast<const float*>(prevPts.data()),
+                                      reinterpret_cast<const float*>(currPts.data()), n, cameraK.val, recPose.R.val,
+                                      recPose.t.val, recPose.mask.data, &numInliers),
+                     "sfm_recover_pose");
+        return numInliers > minInliers;
     }
 };
 

@@ -140,6 +140,33 @@ static int run_corners(const char* in, const char* out) {
     return 0;
 }
 
+static int run_pose(const char* in, const char* out) {
+    Reader r(in);
+    const int n = r.i32(), minInliers = r.i32();
+    const double prob = r.f64(), threshold = r.f64();
+    cvx::Matx33d K;
+    r.raw(K.val, 72);
+    std::vector<cvx::Point2f> p1(static_cast<size_t>(n)), p2(static_cast<size_t>(n));
+    r.raw(p1.data(), size_t(n) * 8);
+    r.raw(p2.data(), size_t(n) * 8);
+    // Source Files/app_solver.cpp constructs it from the peMethod / peProb / peThresh / peMinInl settings
+    sfm_hip::RecoveryPose recPose("ransac", prob, threshold, unsigned(minInliers), "SOLVEPNP_P3P", false, 100u);
+    int numInliers = -1;
+    const bool ok = sfm_hip::Tracking::findCameraPose(recPose, p1, p2, K, minInliers, numInliers);
+    // five points or fewer: false before anything is computed (Source Files/tracking.cpp:92)
+    int untouched = -7;
+    std::vector<cvx::Point2f> few(p1.begin(), p1.begin() + 5);
+    if (sfm_hip::Tracking::findCameraPose(recPose, few, few, K, minInliers, untouched) || untouched != -7) return 3;
+    Writer w(out);
+    w.i32(ok ? 1 : 0);
+    w.i32(numInliers);
+    w.raw(recPose.R.val, 72);
+    w.raw(recPose.t.val, 24);
+    w.i32(recPose.mask.rows);
+    w.raw(recPose.mask.data, size_t(recPose.mask.rows));
+    return 0;
+}
+
 struct Camera {  // the part of CameraParameters triangulateCloud reads
     cvx::Matx33d K33d;
 };
@@ -247,6 +274,7 @@ int main(int argc, char** argv) {
         if (mode == "match") return run_match(argv[2], argv[3]);
         if (mode == "flow") return run_flow(argv[2], argv[3]);
         if (mode == "corners") return run_corners(argv[2], argv[3]);
+        if (mode == "pose") return run_pose(argv[2], argv[3]);
         if (mode == "tri") return run_tri(argv[2], argv[3]);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "adapter_check: %s\n", e.what());

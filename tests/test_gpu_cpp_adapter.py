@@ -174,3 +174,31 @@ def test_generate_flow_features(oracle, tmp_path):
     want = oracle.good_features(img, 150, 0.01, 8.0)
     assert len(want) == 150
     assert np.array_equal(pts[0], [1.5, 2.5]) and np.array_equal(pts[1:], want)
+
+
+def test_find_camera_pose(oracle, tmp_path):
+    """sfm_hip::Tracking::findCameraPose against the same steps done with the oracle."""
+    n = 1800
+    s = synth.triangulation_set(n, seed=71, sigma=0.2, outliers=0.0)
+    rng = np.random.default_rng(72)
+    p1, p2 = s["p1"], s["p2"].copy()
+    bad = rng.random(n) < 0.25
+    p2[bad] = np.stack([rng.uniform(0, 1280, bad.sum()), rng.uniform(0, 720, bad.sum())], 1).astype(np.float32)
+    K = np.ascontiguousarray(s["K"], dtype=np.float64)
+    payload = struct.pack("<iidd", n, 10, 0.99, 0.5) + K.tobytes() + p1.tobytes() + p2.tobytes()
+    out = Cursor(run("pose", payload, tmp_path))
+    ok, n_in = out.i32(), out.i32()
+    R = out.arr("<f8", 9).reshape(3, 3)
+    t = out.arr("<f8", 3)
+    rows = out.i32()
+    mask = out.arr("u1", rows)
+    E, omask, _ = oracle.find_essential(p1, p2, K, 0, 0.99, 0.5)
+    assert len(E) == 1 and rows == n
+    if oracle.essential_residual(E[0], p1[0], p2[0], K) > 1e-3:
+        assert ok == 0 and np.array_equal(mask, omask)
+        return
+    cnt, oR, ot, omask2 = oracle.recover_pose(E[0], p1, p2, K, omask)
+    assert ok == int(cnt > 10) and n_in == cnt
+    assert np.array_equal(mask, omask2)
+    np.testing.assert_allclose(R, oR, atol=1e-8)
+    np.testing.assert_allclose(t, ot, atol=1e-8)

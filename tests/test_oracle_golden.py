@@ -255,3 +255,69 @@ def test_good_features_golden(oracle, name):
     pts, ncand = oracle.good_features(g[f"img_{name}"], int(mc), q, md, return_candidates=True)
     assert ncand == int(g[f"ncand_{name}"][0])
     assert np.array_equal(pts, g[f"pts_{name}"])
+
+
+def _exact_two_view(n, seed):
+    """Noise-free projections (float64) of random points into two known cameras."""
+    from sfm_amd import synth
+
+    s = synth.triangulation_set(n, seed=seed, sigma=0.0, outliers=0.0)
+    t = s["t"]
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = tx @ s["R"]
+    return s, E / np.linalg.norm(E)
+
+
+def test_oracle_five_point_known_answers(oracle):
+    """The five-point restatement against its defining properties and a known geometry:
+    every solution satisfies the five epipolar equations, is singular with two equal
+    singular values, and one of them is the matrix the points were generated with."""
+    s, E_true = _exact_two_view(40, 3)
+    Kinv = np.linalg.inv(s["K"])
+    for start in (0, 5, 10, 20):
+        h1 = np.c_[s["p1"][start:start + 5].astype(np.float64), np.ones(5)] @ Kinv.T
+        h2 = np.c_[s["p2"][start:start + 5].astype(np.float64), np.ones(5)] @ Kinv.T
+        Es = oracle.em_5point(h1[:, :2], h2[:, :2])
+        assert 1 <= len(Es) <= 10
+        for E in Es:
+            assert np.abs(np.einsum("ni,ij,nj->n", h2, E, h1)).max() < 1e-12
+            sv = np.linalg.svd(E, compute_uv=False)
+            assert sv[2] < 1e-8 and abs(sv[0] - sv[1]) < 1e-6
+            assert abs(np.linalg.norm(E) - 1) < 1e-12
+        # float32 pixel coordinates limit how exactly the true matrix satisfies the equations
+        assert min(min(np.abs(E - E_true).max(), np.abs(E + E_true).max()) for E in Es) < 1e-3
+
+
+def test_oracle_essential_subsets_and_pose(oracle):
+    """Draws (the generator's recurrence evaluated here), RANSAC on contaminated data, and
+    recoverPose returning the generating rotation and translation direction."""
+    state = (1 << 64) - 1
+    want = []
+    for _ in range(10):
+        state = (state & 0xFFFFFFFF) * 4164903690 + (state >> 32)
+        want.append((state & 0xFFFFFFFF) % 1000)
+    subs = oracle.em_subsets(1000, 2)
+    assert len(set(want[:5])) == 5 and subs[0].tolist() == want[:5]
+
+    s, E_true = _exact_two_view(1500, 4)
+    rng = np.random.default_rng(5)
+    p2 = s["p2"].copy()
+    bad = rng.random(1500) < 0.3
+    p2[bad] = np.stack([rng.uniform(0, 1280, bad.sum()), rng.uniform(0, 720, bad.sum())], 1)
+    E, mask, iters = oracle.find_essential(s["p1"], p2, s["K"], 0, 0.99, 0.5)
+    assert len(E) == 1 and 1 <= iters <= 1000
+    kept = mask.astype(bool)
+    assert (~bad)[kept].mean() > 0.99 and kept.sum() > 0.9 * (~bad).sum()
+    assert min(np.abs(E[0] - E_true).max(), np.abs(E[0] + E_true).max()) < 1e-3
+    cnt, R, t, mask2 = oracle.recover_pose(E[0], s["p1"], p2, s["K"], mask)
+    assert cnt > 0.9 * kept.sum() and not (mask2 & ~mask).any()
+    np.testing.assert_allclose(R, s["R"], atol=1e-3)
+    assert t @ (s["t"] / np.linalg.norm(s["t"])) > 0.9999
+    # decomposeEssentialMat: proper rotations, unit translation, E = [t]x R up to sign
+    R1, R2, tt = oracle.decompose_essential(E_true)
+    for Rk in (R1, R2):
+        assert abs(np.linalg.det(Rk) - 1) < 1e-12 and np.abs(Rk @ Rk.T - np.eye(3)).max() < 1e-12
+    assert abs(np.linalg.norm(tt) - 1) < 1e-12
+    assert min(np.abs(Rk - s["R"]).max() for Rk in (R1, R2)) < 1e-6
+    # fewer than five points: nothing
+    assert len(oracle.find_essential(s["p1"][:4], p2[:4], s["K"])[0]) == 0
