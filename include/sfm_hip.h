@@ -165,6 +165,21 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
 size_t sfm_pyrlk_workspace(int n_pairs, int width, int height, int win_w, int win_h,
                            int max_level);
 
+/* The filters between computeFlow and findCameraPose (ProcesingAdds::filterPointsByStatusMask
+ * and filterPointsByBoundary, Source Files/feature_processing.cpp:332-358, called at
+ * Source Files/app_solver.cpp:69-70), on device-resident tracking results of n_pairs image
+ * pairs (n slots each): correspondence i of a pair is kept when d_status is set and the current
+ * point lies in the rectangle (x <= pt.x < x + w, y <= pt.y < y + h as cv::Rect::contains;
+ * w or h <= 0: no boundary test); kept correspondences are written in order to the front of
+ * the pair's n output slots and counted in d_counts.  d_valid (optional) gives the number of
+ * meaningful input slots per pair (e.g. the corner count of sfm_good_features_dev).
+ * The reference's loops never advance their index correction, so after the first removal they
+ * test one element and erase another (and can index past the end); this entry point
+ * implements the filter they evidently intend.  Not in place. */
+int sfm_filter_tracked_dev(sfm_ctx* ctx, const float* d_prev_pts, const float* d_curr_pts, const uint8_t* d_status,
+                           const int32_t* d_valid, int n_pairs, int n, int bound_x, int bound_y, int bound_w,
+                           int bound_h, float* d_prev_out, float* d_curr_out, int32_t* d_counts);
+
 /* ---- triangulation ------------------------------------------------------ */
 
 /* Reconstruction::triangulateCloud with pointsToRGBCloud, Source Files/

@@ -42,6 +42,7 @@ EXPORTS = [
     "sfm_find_essential", "sfm_find_essential_dev", "sfm_find_essential_workspace",
     "sfm_recover_pose", "sfm_recover_pose_dev", "sfm_recover_pose_workspace",
     "sfm_find_camera_pose_dev", "sfm_find_camera_pose_workspace",
+    "sfm_filter_tracked_dev",
 ]
 
 
@@ -361,6 +362,14 @@ class Context:
     def find_essential_workspace(n_problems, problem_stride, max_iters=1000):
         return int(lib().sfm_find_essential_workspace(C.c_int(n_problems), C.c_size_t(problem_stride),
                                                       C.c_int(max_iters)))
+
+    def filter_tracked_dev(self, d_prev, d_curr, d_status, d_valid, n_pairs, n, boundary, d_prev_out, d_curr_out,
+                           d_counts):
+        """Status + boundary filter of tracked points; boundary = (x, y, w, h) or None."""
+        bx, by, bw, bh = boundary if boundary is not None else (0, 0, 0, 0)
+        self.check(lib().sfm_filter_tracked_dev(
+            self._h, _ptr(d_prev), _ptr(d_curr), _ptr(d_status), _ptr(d_valid), C.c_int(n_pairs), C.c_int(n),
+            C.c_int(bx), C.c_int(by), C.c_int(bw), C.c_int(bh), _ptr(d_prev_out), _ptr(d_curr_out), _ptr(d_counts)))
 
     def recover_pose(self, E, pts1, pts2, K, mask=None):
         """cv::recoverPose(E, pts1, pts2, K, R, t, mask): returns (count, R [3,3], t [3], mask)."""

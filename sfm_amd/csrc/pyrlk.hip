@@ -808,9 +808,75 @@ int check_lk_args(sfm_ctx* ctx, int width, int height, size_t stride, int n, int
     return SFM_OK;
 }
 
+// The filter the reference applies between computeFlow and findCameraPose
+// (ProcesingAdds::filterPointsByStatusMask then filterPointsByBoundary, Source Files/
+// feature_processing.cpp:332-358, called at Source Files/app_solver.cpp:69-70): keep the
+// correspondences whose status is set and whose current point lies inside the boundary
+// rectangle, both lists in step and in order.  One workgroup per image pair.
+__global__ __launch_bounds__(1024) void lk_filter_kernel(const float2* __restrict__ prev, const float2* __restrict__ curr,
+                                                         const uint8_t* __restrict__ status,
+                                                         const int32_t* __restrict__ valid, int n, float bx, float by,
+                                                         float bw, float bh, float2* __restrict__ prev_out,
+                                                         float2* __restrict__ curr_out, int32_t* __restrict__ counts) {
+    __shared__ int wave_count[16];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t base = (size_t)p * n;
+    const int n_in = valid ? min(max(valid[p], 0), n) : n;
+    int running = 0;
+    for (int i0 = 0; i0 < n_in; i0 += 1024) {
+        const int i = i0 + tid;
+        bool ok = false;
+        float2 a = make_float2(0.f, 0.f), b = a;
+        if (i < n_in) {
+            a = prev[base + i];
+            b = curr[base + i];
+            ok = status[base + i] != 0;
+            // cv::Rect_<int>::contains(Point2f): x <= pt.x < x + width, y <= pt.y < y + height
+            if (bw > 0.f && bh > 0.f) ok = ok && bx <= b.x && b.x < bx + bw && by <= b.y && b.y < by + bh;
+        }
+        const unsigned long long ballot = __ballot(ok);
+        const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_count[wave] = __popcll(ballot);
+        __syncthreads();
+        int offset = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = wave_count[w];
+            offset += w < wave ? c : 0;
+            total += c;
+        }
+        if (ok) {
+            prev_out[base + running + offset + prefix] = a;
+            curr_out[base + running + offset + prefix] = b;
+        }
+        running += total;
+        __syncthreads();
+    }
+    if (tid == 0) counts[p] = running;
+}
+
 }  // namespace
 
 extern "C" {
+
+int sfm_filter_tracked_dev(sfm_ctx* ctx, const float* d_prev_pts, const float* d_curr_pts, const uint8_t* d_status,
+                           const int32_t* d_valid, int n_pairs, int n, int bound_x, int bound_y, int bound_w,
+                           int bound_h, float* d_prev_out, float* d_curr_out, int32_t* d_counts) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (n_pairs < 0 || n < 0) return set_error(ctx, SFM_E_INVALID, "negative count");
+    if (n_pairs == 0) return SFM_OK;
+    if (!d_prev_pts || !d_curr_pts || !d_status || !d_prev_out || !d_curr_out || !d_counts)
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (d_prev_out == d_prev_pts || d_curr_out == d_curr_pts)
+        return set_error(ctx, SFM_E_INVALID, "the filter does not work in place");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(lk_filter_kernel, dim3(n_pairs), dim3(1024), 0, ctx->stream,
+                       reinterpret_cast<const float2*>(d_prev_pts), reinterpret_cast<const float2*>(d_curr_pts), d_status,
+                       d_valid, n, (float)bound_x, (float)bound_y, (float)bound_w, (float)bound_h,
+                       reinterpret_cast<float2*>(d_prev_out), reinterpret_cast<float2*>(d_curr_out), d_counts);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
 
 size_t sfm_pyrlk_workspace(int n_pairs, int width, int height, int win_w, int win_h,
                            int max_level) {
