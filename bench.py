@@ -696,15 +696,14 @@ def run_f3(args, rank, world, local):
     n_tex = min(4, P)
     frames = np.stack([synth.to_u8(synth.texture(LK_H, LK_W, seed=42 + 17 * i + 1000 * rank))
                        for i in range(n_tex)])
-    d_frames = torch.from_numpy(frames).to(dev)
+    d_frames = torch.from_numpy(frames[np.arange(P) % n_tex]).to(dev)   # P frames, one batched call
     d_pts = torch.zeros((P, MAXC, 2), dtype=torch.float32, device=dev)
     d_info = torch.zeros((P, 3), dtype=torch.int32, device=dev)
-    ctx.reserve(capi.Context.good_features_workspace(LK_W, LK_H))
+    ctx.reserve(capi.Context.good_features_batch_workspace(P, LK_W, LK_H))
 
     def step():
-        for p in range(P):
-            ctx.good_features_dev(d_frames[p % n_tex], LK_W, LK_H, LK_W, MAXC, QUAL, MIND, d_pts[p], MAXC,
-                                  d_info[p])
+        ctx.good_features_batch_dev(d_frames, P, LK_W * LK_H, LK_W, LK_H, LK_W, MAXC, QUAL, MIND, d_pts, MAXC,
+                                    d_info)
 
     dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, ctx)
     info = d_info.cpu().numpy()
@@ -793,14 +792,14 @@ def run_vo(args, rank, world, local):
     d_E, d_R, d_t = z((P, 10, 9), torch.float64), z((P, 9), torch.float64), z((P, 3), torch.float64)
     d_mask, d_found, d_inl = z((P, MAXC), torch.uint8), z(P, torch.int32), z(P, torch.int32)
     d_valid = z(P, torch.int32)
-    ctx.reserve(max(capi.Context.good_features_workspace(LK_W, LK_H),
+    ctx.reserve(max(capi.Context.good_features_batch_workspace(P, LK_W, LK_H),
                     capi.Context.pyrlk_workspace(P, LK_W, LK_H, LK_WIN, LK_MAXLEVEL),
                     capi.Context.find_camera_pose_workspace(P, MAXC)))
     bound = (8, 8, LK_W - 16, LK_H - 16)
 
     def step():
-        for p in range(P):
-            ctx.good_features_dev(d_prev[p], LK_W, LK_H, LK_W, MAXC, 0.01, 10.0, d_corners[p], MAXC, d_info[p])
+        ctx.good_features_batch_dev(d_prev, P, LK_W * LK_H, LK_W, LK_H, LK_W, MAXC, 0.01, 10.0, d_corners, MAXC,
+                                    d_info)
         ctx.pyrlk_batch_dev(d_prev, d_curr, P, LK_W * LK_H, LK_W, LK_H, LK_W, d_corners, MAXC, LK_WIN,
                             LK_MAXLEVEL, 3, LK_COUNT, LK_EPS, 1e-4, 10.0, d_next, d_status, d_err)
         d_valid.copy_(d_info[:, 0])

@@ -276,7 +276,7 @@ size_t sfm_epipolar_filter_pairs_workspace(int n_pairs, int cap, int max_iters);
  * img: w x h 8-bit gray, `stride` bytes between rows, host memory.  corners: room for `cap`
  * (x, y) float pairs; *count receives the number found, strongest first.  max_corners == 0
  * means no limit (OpenCV's convention); quality > 0, min_distance >= 0 as OpenCV asserts.
- * The image must be at least 3 x 3. */
+ * The image must be at least 3 x 3 and at most 2^26 pixels. */
 int sfm_good_features(sfm_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, int max_corners,
                       double quality, double min_distance, float* corners, int cap, int* count);
 
@@ -289,6 +289,15 @@ int sfm_good_features_dev(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size
                           double quality, double min_distance, int max_candidates, float* d_corners,
                           int cap, int32_t* d_info);
 size_t sfm_good_features_workspace(int w, int h, int max_candidates);
+
+/* The same for up to 64 equally sized device-resident images per call (image i at d_imgs +
+ * i * image_stride bytes; corners of image i at d_corners + i * cap * 2 floats, its three
+ * counters at d_info + 3 i).  One set of launches serves the whole batch: for single video
+ * frames most of the time is the gaps between some thirty short kernels. */
+int sfm_good_features_batch_dev(sfm_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_stride, int w, int h,
+                                size_t stride, int max_corners, double quality, double min_distance,
+                                int max_candidates, float* d_corners, int cap, int32_t* d_info);
+size_t sfm_good_features_batch_workspace(int n_images, int w, int h, int max_candidates);
 
 /* cv::cornerMinEigenVal(image, eig, 3, 3), the first stage of the above: d_eig is [h][w]
  * float, dense. */

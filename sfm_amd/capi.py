@@ -38,6 +38,7 @@ EXPORTS = [
     "sfm_fundamental", "sfm_fundamental_dev", "sfm_fundamental_workspace",
     "sfm_epipolar_filter_pairs_dev", "sfm_epipolar_filter_pairs_workspace",
     "sfm_good_features", "sfm_good_features_dev", "sfm_good_features_workspace",
+    "sfm_good_features_batch_dev", "sfm_good_features_batch_workspace",
     "sfm_min_eigen_val_dev",
     "sfm_find_essential", "sfm_find_essential_dev", "sfm_find_essential_workspace",
     "sfm_recover_pose", "sfm_recover_pose_dev", "sfm_recover_pose_workspace",
@@ -69,7 +70,7 @@ def lib():
         l.sfm_ctx_destroy.restype = None
         l.sfm_ctx_destroy.argtypes = [C.c_void_p]
         for name in ("sfm_match_pairs_workspace", "sfm_pyrlk_workspace", "sfm_fundamental_workspace",
-                     "sfm_epipolar_filter_pairs_workspace", "sfm_good_features_workspace", "sfm_find_essential_workspace", "sfm_recover_pose_workspace",
+                     "sfm_epipolar_filter_pairs_workspace", "sfm_good_features_workspace", "sfm_good_features_batch_workspace", "sfm_find_essential_workspace", "sfm_recover_pose_workspace",
                      "sfm_find_camera_pose_workspace"):
             if hasattr(l, name):
                 getattr(l, name).restype = C.c_size_t
@@ -420,6 +421,18 @@ class Context:
             self._h, _ptr(d_img), C.c_int(w), C.c_int(h), C.c_size_t(stride), C.c_int(max_corners),
             C.c_double(quality), C.c_double(min_distance), C.c_int(max_candidates), _ptr(d_corners),
             C.c_int(cap), _ptr(d_info)))
+
+    def good_features_batch_dev(self, d_imgs, n_images, image_stride, w, h, stride, max_corners, quality,
+                                min_distance, d_corners, cap, d_info, max_candidates=0):
+        self.check(lib().sfm_good_features_batch_dev(
+            self._h, _ptr(d_imgs), C.c_int(n_images), C.c_size_t(image_stride), C.c_int(w), C.c_int(h),
+            C.c_size_t(stride), C.c_int(max_corners), C.c_double(quality), C.c_double(min_distance),
+            C.c_int(max_candidates), _ptr(d_corners), C.c_int(cap), _ptr(d_info)))
+
+    @staticmethod
+    def good_features_batch_workspace(n_images, w, h, max_candidates=0):
+        return int(lib().sfm_good_features_batch_workspace(C.c_int(n_images), C.c_int(w), C.c_int(h),
+                                                           C.c_int(max_candidates)))
 
     @staticmethod
     def good_features_workspace(w, h, max_candidates=0):

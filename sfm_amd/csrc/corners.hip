@@ -5,7 +5,7 @@
 //   1. corner_eig_kernel     Sobel -> products -> 3x3 box sum -> smaller eigenvalue, one pass
 //                            over the image through LDS tiles; image maximum by atomics.
 //   2. corner_pick_kernel    threshold at max * qualityLevel, 3x3 local maxima of the interior,
-//                            appended as sortable keys (value bits << 32 | y * w + x).
+//                            appended as sortable keys (image << 58 | value bits << 26 | y * w + x).
 //   3. radix sort, descending: by value, ties by address, both descending, as OpenCV's
 //      std::sort with greaterThanPtr orders its pointers.
 //   4. corner_rank_kernel    position -> rank image (which also carries each candidate's state).
@@ -26,6 +26,11 @@
 //                            on another).  Rounds after the end exit at once; a single-wave
 //                            sequential pass settles whatever a fixed number of rounds left open.
 //   6. corner_emit_kernel    the kept candidates, in rank order, up to maxCorners.
+//
+// Every kernel takes a batch of equally sized images (one grid dimension is the image); the
+// candidates of all images are sorted by ONE radix sort, the image number riding in the top
+// bits of the key.  For a single 1280x720 frame two thirds of the time are launch gaps between
+// ~30 short kernels; a batch shares them.
 //
 // All float arithmetic is unfused and ordered as in the CPU restatement: Sobel smoothing
 // (s0 + s2) * k1 + s1 * k0 with the scale 1 / (4 * 3 * 255) folded into the taps, box sums
@@ -50,11 +55,18 @@ constexpr int kMaxDistance = 128;  // largest minDistance: the disc's offsets ar
 // per round r: candidates still open after it, candidates kept in it
 enum { C_FOUND = 0, C_OVERFLOW, C_OPEN, C_KEPT = C_OPEN + kSelectRounds, C_COUNT = C_KEPT + kSelectRounds };
 constexpr int kStateShift = 30;  // rank image entries: rank | state << 30, or -1
+constexpr int kPosBits = 26, kImageShift = 58, kMaxImages = 64;  // key = image | value bits | position
+constexpr int kCtrlWords = 64;  // cleared words per image: maximum, counters
 
 struct CornerArgs {
     const uint8_t* img;
     int w, h;
     size_t stride;
+    int n_images, image;    // batch size; the image these pointers belong to (after image_view)
+    size_t img_stride;      // bytes between images
+    float2* corners;        // [image][cap_out]
+    int cap_out;
+    int32_t* info;          // [image][3]
     float* eig;             // [h][w]
     unsigned* max_bits;     // ordered bits of the image maximum
     unsigned long long* keys;     // [cap] appended candidates
@@ -66,6 +78,26 @@ struct CornerArgs {
     double quality, min_distance;
     int max_corners;
 };
+
+// The arguments of image `im` of the batch: every per-image array moved to its slice.  The
+// sorted keys of image im follow those of the images above it (descending sort).
+__device__ __forceinline__ CornerArgs image_view(CornerArgs a, int im) {
+    const size_t px = (size_t)a.w * a.h;
+    a.image = im;
+    a.img += (size_t)im * a.img_stride;
+    a.eig += (size_t)im * px;
+    a.rank += (size_t)im * px;
+    a.max_bits += (size_t)im * kCtrlWords;
+    a.counters += (size_t)im * kCtrlWords;
+    a.keys += (size_t)im * a.cap;
+    a.sorted += (size_t)(a.n_images - 1 - im) * a.cap;
+    a.state += (size_t)im * a.cap;
+    a.corners += (size_t)im * a.cap_out;
+    a.info += 3 * im;
+    return a;
+}
+
+__device__ __forceinline__ unsigned key_position(unsigned long long key) { return (unsigned)(key & ((1ull << kPosBits) - 1)); }
 
 __device__ __forceinline__ int reflect101(int i, int n) {
     i = i < 0 ? -i : i;
@@ -82,7 +114,8 @@ __device__ __forceinline__ float from_ordered_bits(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-__global__ __launch_bounds__(256) void corner_eig_kernel(CornerArgs a) {
+__global__ __launch_bounds__(256) void corner_eig_kernel(CornerArgs batch) {
+    const CornerArgs a = image_view(batch, blockIdx.z);
     __shared__ uint8_t s_img[kTileH + 4][kTileW + 4];
     __shared__ float2 s_d[kTileH + 2][kTileW + 2];
     __shared__ unsigned s_max;
@@ -155,9 +188,17 @@ __global__ __launch_bounds__(256) void corner_eig_kernel(CornerArgs a) {
     if (tid == 0 && s_max) atomicMax(a.max_bits, s_max);
 }
 
+// Unused key slots sort behind the candidates of their own image.
+__global__ void corner_fill_kernel(CornerArgs batch) {
+    const size_t total = (size_t)batch.n_images * batch.cap;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        batch.keys[i] = (unsigned long long)(i / batch.cap) << kImageShift;
+}
+
 constexpr int kPickRows = 32;  // rows per workgroup of the candidate pass (8 per wave)
 
-__global__ __launch_bounds__(256) void corner_pick_kernel(CornerArgs a) {
+__global__ __launch_bounds__(256) void corner_pick_kernel(CornerArgs batch) {
+    const CornerArgs a = image_view(batch, blockIdx.z);
     __shared__ int s_wave[4];
     __shared__ int s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -206,7 +247,8 @@ __global__ __launch_bounds__(256) void corner_pick_kernel(CornerArgs a) {
         if ((ballots[k] >> lane) & 1ULL) {
             const int slot = base + (int)__popcll(ballots[k] & ((1ULL << lane) - 1ULL));
             if (slot < a.cap)
-                a.keys[slot] = ((unsigned long long)ordered_bits(vals[k]) << 32) | (unsigned)(y * a.w + x);
+                a.keys[slot] = ((unsigned long long)a.image << kImageShift) |
+                               ((unsigned long long)ordered_bits(vals[k]) << kPosBits) | (unsigned)(y * a.w + x);
             else
                 a.counters[C_OVERFLOW] = 1;
         }
@@ -230,10 +272,11 @@ __device__ __forceinline__ void store_state(const CornerArgs& a, int i, unsigned
 }
 
 // Ranks and the first prefix to work on.
-__global__ __launch_bounds__(256) void corner_rank_kernel(CornerArgs a) {
+__global__ __launch_bounds__(256) void corner_rank_kernel(CornerArgs batch) {
+    const CornerArgs a = image_view(batch, blockIdx.y);
     const int n = candidate_count(a);
     const int t0 = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    for (int i = t0; i < n; i += nt) a.rank[(unsigned)(a.sorted[i] & 0xffffffffu)] = i;
+    for (int i = t0; i < n; i += nt) a.rank[key_position(a.sorted[i])] = i;
 }
 
 // The disc "closer than minDistance" on the pixel grid.  OpenCV tests float dx*dx + dy*dy <
@@ -300,8 +343,9 @@ __device__ int window_of_round(const CornerArgs& a, int n, int round) {
     return window;
 }
 
-__global__ __launch_bounds__(256) void corner_select_kernel(CornerArgs a, int round) {
+__global__ __launch_bounds__(256) void corner_select_kernel(CornerArgs batch, int round) {
     __shared__ int s_open, s_kept;
+    const CornerArgs a = image_view(batch, blockIdx.y);
     const int n = candidate_count(a);
     const int window = window_of_round(a, n, round);
     if (window == 0) return;
@@ -313,7 +357,7 @@ __global__ __launch_bounds__(256) void corner_select_kernel(CornerArgs a, int ro
     int open = 0, kept = 0;
     for (int i = wave; i < window; i += n_waves) {
         if (load_state(a, i) != 0) continue;
-        const unsigned pos = (unsigned)(a.sorted[i] & 0xffffffffu);
+        const unsigned pos = key_position(a.sorted[i]);
         const int s = a.min_distance >= 1 ? decide(a, i, pos, lane, disc) : 1;
         open += s == 0;
         kept += s == 1;
@@ -328,7 +372,8 @@ __global__ __launch_bounds__(256) void corner_select_kernel(CornerArgs a, int ro
 }
 
 // Whatever the rounds left open, in order, by one wave.
-__global__ __launch_bounds__(64) void corner_settle_kernel(CornerArgs a) {
+__global__ __launch_bounds__(64) void corner_settle_kernel(CornerArgs batch) {
+    const CornerArgs a = image_view(batch, blockIdx.x);
     const int n = candidate_count(a);
     if (window_of_round(a, n, kSelectRounds) == 0) return;
     const int lane = threadIdx.x;
@@ -337,7 +382,7 @@ __global__ __launch_bounds__(64) void corner_settle_kernel(CornerArgs a) {
     for (int i = 0; i < n; ++i) {
         int s = load_state(a, i);
         if (s == 0) {
-            const unsigned pos = (unsigned)(a.sorted[i] & 0xffffffffu);
+            const unsigned pos = key_position(a.sorted[i]);
             s = a.min_distance >= 1 ? decide(a, i, pos, lane, disc) : 1;  // every stronger one is settled
             if (lane == 0) store_state(a, i, pos, s);
             __threadfence();
@@ -349,9 +394,12 @@ __global__ __launch_bounds__(64) void corner_settle_kernel(CornerArgs a) {
 
 // out[0] = corners written, out[1] = candidates, out[2] = 1 if candidates were lost to the
 // capacity.
-__global__ __launch_bounds__(1024) void corner_emit_kernel(CornerArgs a, float2* __restrict__ corners, int cap_out,
-                                                           int32_t* __restrict__ out) {
+__global__ __launch_bounds__(1024) void corner_emit_kernel(CornerArgs batch) {
     __shared__ int wave_count[16];
+    const CornerArgs a = image_view(batch, blockIdx.x);
+    float2* corners = a.corners;
+    int32_t* out = a.info;
+    const int cap_out = a.cap_out;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = candidate_count(a);
     int limit = cap_out;
@@ -373,7 +421,7 @@ __global__ __launch_bounds__(1024) void corner_emit_kernel(CornerArgs a, float2*
         }
         const int slot = running + offset + prefix;
         if (ok && slot < limit) {
-            const unsigned pos = (unsigned)(a.sorted[i] & 0xffffffffu);
+            const unsigned pos = key_position(a.sorted[i]);
             const int y = (int)(pos / (unsigned)a.w), x = (int)(pos - (unsigned)y * a.w);
             corners[slot] = make_float2((float)x, (float)y);
         }
@@ -394,10 +442,10 @@ int default_capacity(int w, int h) {
     return (int)std::min<size_t>(px, px / 4 + 1024);
 }
 
-size_t sort_temp_bytes(int cap) {
+size_t sort_temp_bytes(size_t slots) {
     size_t bytes = 0;
     (void)rocprim::radix_sort_keys_desc(nullptr, bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                        (size_t)cap, 0, 64, nullptr);
+                                        slots, 0, 64, nullptr);
     return bytes;
 }
 
@@ -406,84 +454,90 @@ struct CornerBuffers {
     int32_t* rank;
     unsigned long long *keys, *sorted;
     int32_t* state;
-    unsigned* max_bits;
-    int32_t* counters;
-    int32_t* out;
+    unsigned* ctrl;  // per image kCtrlWords: the maximum, then the counters
     void* sort_temp;
     size_t sort_bytes;
 };
 
-CornerBuffers carve_corners(Carver& c, int w, int h, int cap) {
+CornerBuffers carve_corners(Carver& c, int n_images, int w, int h, int cap) {
     CornerBuffers b;
-    const size_t px = (size_t)w * h;
+    const size_t px = (size_t)w * h * n_images, slots = (size_t)cap * n_images;
     b.eig = c.take<float>(px);
     b.rank = c.take<int32_t>(px);
-    b.keys = c.take<unsigned long long>((size_t)cap);
-    b.sorted = c.take<unsigned long long>((size_t)cap);
-    b.state = c.take<int32_t>((size_t)cap);
-    // one block to clear: maximum, counters, result
-    b.max_bits = c.take<unsigned>(64);
-    b.counters = reinterpret_cast<int32_t*>(b.max_bits) + 4;
-    b.out = b.counters + C_COUNT;
-    static_assert(4 + C_COUNT + 3 <= 64, "the cleared block is 64 words");
-    b.sort_bytes = sort_temp_bytes(cap);
+    b.keys = c.take<unsigned long long>(slots);
+    b.sorted = c.take<unsigned long long>(slots);
+    b.state = c.take<int32_t>(slots);
+    b.ctrl = c.take<unsigned>((size_t)kCtrlWords * n_images);
+    static_assert(4 + C_COUNT <= kCtrlWords, "the counters fit the cleared block");
+    b.sort_bytes = sort_temp_bytes(slots);
     b.sort_temp = c.take<char>(b.sort_bytes);
     return b;
 }
 
-// Enqueues the whole detection; the result (count, candidates, overflow) lands in b.out.
-int run_corners(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size_t stride, int max_corners, double quality,
-                double min_distance, float* d_corners, int cap_out, int cap, const CornerBuffers& b) {
+// Enqueues the detection for a batch of images; the results land in d_corners and d_info.
+int run_corners(sfm_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_stride, int w, int h, size_t stride,
+                int max_corners, double quality, double min_distance, float* d_corners, int cap_out, int32_t* d_info,
+                int cap, const CornerBuffers& b) {
     CornerArgs a{};
-    a.img = d_img;
+    a.img = d_imgs;
     a.w = w;
     a.h = h;
     a.stride = stride;
+    a.n_images = n_images;
+    a.img_stride = image_stride;
+    a.corners = reinterpret_cast<float2*>(d_corners);
+    a.cap_out = cap_out;
+    a.info = d_info;
     a.eig = b.eig;
-    a.max_bits = b.max_bits;
+    a.max_bits = b.ctrl;
     a.keys = b.keys;
     a.sorted = b.sorted;
     a.rank = b.rank;
     a.state = b.state;
-    a.counters = b.counters;
+    a.counters = reinterpret_cast<int32_t*>(b.ctrl) + 4;
     a.cap = cap;
     a.quality = quality;
     a.min_distance = min_distance;
     a.max_corners = max_corners;
     hipStream_t s = ctx->stream;
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.max_bits, 0, 64 * sizeof(unsigned), s));
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.keys, 0, sizeof(unsigned long long) * (size_t)cap, s));
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.rank, 0xff, sizeof(int32_t) * (size_t)w * h, s));
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.state, 0, sizeof(int32_t) * (size_t)cap, s));
+    const size_t px = (size_t)w * h * n_images, slots = (size_t)cap * n_images;
+    const unsigned n = (unsigned)n_images;
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.ctrl, 0, sizeof(unsigned) * kCtrlWords * n_images, s));
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.rank, 0xff, sizeof(int32_t) * px, s));
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.state, 0, sizeof(int32_t) * slots, s));
     {
         KernelTimer timer(ctx, KID_CORNER_EIG);
-        hipLaunchKernelGGL(corner_eig_kernel, dim3((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH), dim3(256), 0,
+        hipLaunchKernelGGL(corner_eig_kernel, dim3((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH, n), dim3(256), 0,
                            s, a);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
-    if (w > 2 && h > 2) {
+    {
         KernelTimer timer(ctx, KID_CORNER_PICK);
-        hipLaunchKernelGGL(corner_pick_kernel, dim3((w - 2 + 63) / 64, (h - 2 + kPickRows - 1) / kPickRows), dim3(256), 0,
-                           s, a);
+        hipLaunchKernelGGL(corner_fill_kernel, dim3((unsigned)std::min<size_t>((slots + 255) / 256, 4096)), dim3(256), 0, s,
+                           a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(corner_pick_kernel, dim3((w - 2 + 63) / 64, (h - 2 + kPickRows - 1) / kPickRows, n), dim3(256),
+                           0, s, a);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
     {
         KernelTimer timer(ctx, KID_CORNER_SORT);
         size_t bytes = b.sort_bytes;
-        SFM_HIP_CHECK(ctx, rocprim::radix_sort_keys_desc(b.sort_temp, bytes, b.keys, b.sorted, (size_t)cap, 0, 64, s));
+        SFM_HIP_CHECK(ctx, rocprim::radix_sort_keys_desc(b.sort_temp, bytes, b.keys, b.sorted, slots, 0, 64, s));
     }
     {
         KernelTimer timer(ctx, KID_CORNER_SELECT);
-        hipLaunchKernelGGL(corner_rank_kernel, dim3(256), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(corner_rank_kernel, dim3(256, n), dim3(256), 0, s, a);
         SFM_HIP_CHECK(ctx, hipGetLastError());
+        // about 32 waves per CU over the whole batch, at least 32 workgroups per image
+        const unsigned per_image = (unsigned)std::min(std::max(ctx->num_cus * 32 / n_images, 32), 1024);
         for (int r = 0; r < kSelectRounds; ++r) {
-            hipLaunchKernelGGL(corner_select_kernel, dim3(ctx->num_cus * 4), dim3(256), 0, s, a, r);
+            hipLaunchKernelGGL(corner_select_kernel, dim3(per_image, n), dim3(256), 0, s, a, r);
             SFM_HIP_CHECK(ctx, hipGetLastError());
         }
-        hipLaunchKernelGGL(corner_settle_kernel, dim3(1), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(corner_settle_kernel, dim3(n), dim3(64), 0, s, a);
         SFM_HIP_CHECK(ctx, hipGetLastError());
-        hipLaunchKernelGGL(corner_emit_kernel, dim3(1), dim3(1024), 0, s, a, reinterpret_cast<float2*>(d_corners),
-                           cap_out, b.out);
+        hipLaunchKernelGGL(corner_emit_kernel, dim3(n), dim3(1024), 0, s, a);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
     return SFM_OK;
@@ -492,8 +546,8 @@ int run_corners(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size_t stride,
 int check_corner_args(sfm_ctx* ctx, const void* img, int w, int h, size_t stride, double quality,
                       double min_distance, const void* corners, int cap_out) {
     if (!img || (!corners && cap_out > 0)) return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
-    if (w < 3 || h < 3 || stride < (size_t)w || (size_t)w * h > 0x7fffffffu)
-        return set_error(ctx, SFM_E_INVALID, "image must be at least 3x3, stride >= width, below 2^31 pixels");
+    if (w < 3 || h < 3 || stride < (size_t)w || (size_t)w * h > (1u << kPosBits))
+        return set_error(ctx, SFM_E_INVALID, "image must be at least 3x3, stride >= width, at most 2^26 pixels");
     // OpenCV: CV_Assert(qualityLevel > 0 && minDistance >= 0 && maxCorners >= 0)
     if (!(quality > 0) || !(min_distance >= 0) || cap_out < 0)
         return set_error(ctx, SFM_E_INVALID, "qualityLevel must be > 0, minDistance and the capacity >= 0");
@@ -509,30 +563,44 @@ using namespace sfm;
 
 extern "C" {
 
-size_t sfm_good_features_workspace(int w, int h, int max_candidates) {
-    if (w <= 0 || h <= 0) return 0;
+size_t sfm_good_features_batch_workspace(int n_images, int w, int h, int max_candidates) {
+    if (w <= 0 || h <= 0 || n_images <= 0) return 0;
     const int cap = max_candidates > 0 ? max_candidates : default_capacity(w, h);
     Carver c(nullptr);
-    carve_corners(c, w, h, cap);
+    carve_corners(c, n_images, w, h, cap);
     return c.total();
+}
+
+size_t sfm_good_features_workspace(int w, int h, int max_candidates) {
+    return sfm_good_features_batch_workspace(1, w, h, max_candidates);
+}
+
+int sfm_good_features_batch_dev(sfm_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_stride, int w, int h,
+                                size_t stride, int max_corners, double quality, double min_distance,
+                                int max_candidates, float* d_corners, int cap, int32_t* d_info) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (n_images < 0 || n_images > kMaxImages) return set_error(ctx, SFM_E_INVALID, "between 0 and 64 images per call");
+    if (n_images == 0) return SFM_OK;
+    SFM_RETURN_IF(check_corner_args(ctx, d_imgs, w, h, stride, quality, min_distance, d_corners, cap));
+    if (!d_info || max_corners < 0) return set_error(ctx, SFM_E_INVALID, "d_info is NULL or maxCorners negative");
+    if (n_images > 1 && image_stride < stride * (size_t)(h - 1) + (size_t)w)
+        return set_error(ctx, SFM_E_INVALID, "image stride smaller than an image");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int cand_cap = max_candidates > 0 ? (int)std::min<size_t>(max_candidates, (size_t)w * h) : default_capacity(w, h);
+    cand_cap = std::min(cand_cap, (1 << kStateShift) - 1);  // ranks share a word with the state
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, sfm_good_features_batch_workspace(n_images, w, h, cand_cap), &ws));
+    Carver c(ws);
+    const CornerBuffers b = carve_corners(c, n_images, w, h, cand_cap);
+    return run_corners(ctx, d_imgs, n_images, image_stride, w, h, stride, max_corners, quality, min_distance, d_corners, cap,
+                       d_info, cand_cap, b);
 }
 
 int sfm_good_features_dev(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size_t stride, int max_corners,
                           double quality, double min_distance, int max_candidates, float* d_corners, int cap,
                           int32_t* d_info) {
-    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
-    SFM_RETURN_IF(check_corner_args(ctx, d_img, w, h, stride, quality, min_distance, d_corners, cap));
-    if (!d_info || max_corners < 0) return set_error(ctx, SFM_E_INVALID, "d_info is NULL or maxCorners negative");
-    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    int cand_cap = max_candidates > 0 ? (int)std::min<size_t>(max_candidates, (size_t)w * h) : default_capacity(w, h);
-    cand_cap = std::min(cand_cap, (1 << kStateShift) - 1);  // ranks share a word with the state
-    void* ws;
-    SFM_RETURN_IF(workspace(ctx, sfm_good_features_workspace(w, h, cand_cap), &ws));
-    Carver c(ws);
-    const CornerBuffers b = carve_corners(c, w, h, cand_cap);
-    SFM_RETURN_IF(run_corners(ctx, d_img, w, h, stride, max_corners, quality, min_distance, d_corners, cap, cand_cap, b));
-    SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_info, b.out, 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
-    return SFM_OK;
+    return sfm_good_features_batch_dev(ctx, d_img, 1, 0, w, h, stride, max_corners, quality, min_distance, max_candidates,
+                                       d_corners, cap, d_info);
 }
 
 int sfm_good_features(sfm_ctx* ctx, const uint8_t* img, int w, int h, size_t stride, int max_corners, double quality,
@@ -566,8 +634,8 @@ int sfm_good_features(sfm_ctx* ctx, const uint8_t* img, int w, int h, size_t str
     if (getenv("SFM_CORNER_TRACE")) {  // the rounds of the selection, for tuning
         int32_t c[C_COUNT];
         Carver wc(ctx->ws);
-        const CornerBuffers wb = carve_corners(wc, w, h, default_capacity(w, h));
-        if (hipMemcpy(c, wb.counters, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess) {
+        const CornerBuffers wb = carve_corners(wc, 1, w, h, default_capacity(w, h));
+        if (hipMemcpy(c, wb.ctrl + 4, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "corners: found %d open/kept per round:", c[C_FOUND]);
             for (int r = 0; r < kSelectRounds; ++r) fprintf(stderr, " %d/%d", c[C_OPEN + r], c[C_KEPT + r]);
             fprintf(stderr, "\n");
@@ -594,8 +662,10 @@ int sfm_min_eigen_val_dev(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size
     a.w = w;
     a.h = h;
     a.stride = stride;
+    a.n_images = 1;
     a.eig = d_eig;
     a.max_bits = static_cast<unsigned*>(ws);
+    a.counters = reinterpret_cast<int32_t*>(ws) + 4;
     SFM_HIP_CHECK(ctx, hipMemsetAsync(ws, 0, 256, ctx->stream));
     KernelTimer timer(ctx, KID_CORNER_EIG);
     hipLaunchKernelGGL(corner_eig_kernel, dim3((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH), dim3(256), 0,

@@ -144,3 +144,24 @@ def test_bad_arguments_raise(ctx):
         ctx.good_features(img, 10, 0.01, -1.0)    # ... and minDistance >= 0
     with pytest.raises(capi.SfmError):
         ctx.good_features(img[:2], 10, 0.01, 1.0)  # smaller than the 3x3 neighbourhood
+
+
+def test_batch_of_images_equals_single_calls(ctx, oracle):
+    """Many frames per call: one set of launches, one sort with the image number in the key."""
+    import torch
+
+    h, w, n_img, cap = 240, 320, 5, 400
+    imgs = np.stack([frame(h, w, 70 + i) for i in range(n_img)])
+    imgs[3] = 50                                  # a constant frame in the middle: no corners
+    d_imgs = torch.from_numpy(imgs).cuda()
+    d_pts = torch.zeros((n_img, cap, 2), dtype=torch.float32, device="cuda")
+    d_info = torch.zeros((n_img, 3), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.good_features_batch_dev(d_imgs, n_img, w * h, w, h, w, cap, 0.01, 7.0, d_pts, cap, d_info)
+    ctx.synchronize()
+    info, pts = d_info.cpu().numpy(), d_pts.cpu().numpy()
+    for i in range(n_img):
+        want, ncand = oracle.good_features(imgs[i], cap, 0.01, 7.0, return_candidates=True)
+        assert info[i, 0] == len(want) and info[i, 1] == ncand and info[i, 2] == 0
+        assert np.array_equal(pts[i, : len(want)], want)
+    assert info[3, 0] == 0 and info[0, 0] == cap
