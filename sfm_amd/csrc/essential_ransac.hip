@@ -8,7 +8,7 @@
 // bookkeeping over the scores of the round before and continues the random draws; the solves and
 // the scoring of a round's live iterations run in parallel; a point set whose loop has ended
 // costs later rounds nothing.  Per iteration:
-//   em_solve_kernel   one lane per 5-point sample: null space of the 5x9 epipolar system
+//   em_solve_kernel   one lane per 5-point sample (work arrays in LDS): null space of the 5x9 epipolar system
 //                     (Gauss-Jordan with complete pivoting + Gram-Schmidt), the ten cubic
 //                     constraints det E = 0, E E^T E - tr(E E^T) E / 2 = 0 by polynomial
 //                     products, elimination in Nister's monomial order, the determinant of the
@@ -123,8 +123,22 @@ constexpr Mono make_mono() {
 }
 __constant__ Mono kMono = make_mono();
 
+// The solver's work arrays live in LDS, one column per sample: element i of a sample's array
+// sits kSolveLanes doubles after element i - 1 (scratch memory made every one of the
+// solver's few thousand dependent array accesses an L2 round trip).
+constexpr int kSolveLanes = 16;  // samples per workgroup
+struct Lds {
+    double* p;
+    __device__ __forceinline__ double& operator[](int i) const { return p[i * kSolveLanes]; }
+    __device__ __forceinline__ Lds at(int offset) const { return {p + offset * kSolveLanes}; }
+};
+// doubles per sample
+constexpr int kSolveQ = 45, kSolveEe = 36, kSolveLin = 36, kSolveLam = 180, kSolveA = 200, kSolveB = 39,
+              kSolvePz = 45, kSolveTmp = 60;
+constexpr int kSolveDoubles = kSolveQ + kSolveEe + kSolveLin + kSolveLam + kSolveA + kSolveB + kSolvePz + kSolveTmp;
+
 // out += scale * a * l, l a linear polynomial given by its (x, y, z, 1) coefficients
-__device__ void mul_linear_acc(const double* a, const double* l, double scale, double* out) {
+__device__ void mul_linear_acc(Lds a, Lds l, double scale, Lds out) {
     for (int p = 0; p < 20; ++p) {
         const double ap = a[p];
         if (ap == 0) continue;
@@ -174,7 +188,8 @@ __device__ void solve_poly_generic(const double* coeffs, int n, Cplx* roots) {
 }
 
 // cv::solvePoly for degree 10.  OpenCV sweeps until a sweep changes nothing at all (in
-// practice all 300 times); here the sweeps stop once the corrections are rounding noise.
+// practice all 300 times); here the sweeps stop once the corrections are rounding noise
+// (below 1e-11 relative and no longer shrinking).
 // The usual case (a leading coefficient that does not vanish) keeps coefficients and roots
 // in registers: every loop over them is unrolled.
 __device__ void solve_poly10(const double* coeffs_in, Cplx* roots_out) {
@@ -199,6 +214,7 @@ __device__ void solve_poly10(const double* coeffs_in, Cplx* roots_out) {
             p = c_mul(p, r);
         }
     }
+    double prev_rel = DBL_MAX;
     for (int iter = 0; iter < 300; iter++) {
         double max_rel = 0;
 #pragma unroll
@@ -223,18 +239,23 @@ __device__ void solve_poly10(const double* coeffs_in, Cplx* roots_out) {
             const double rel = sqrt(q.re * q.re + q.im * q.im) / (1.0 + sqrt(p.re * p.re + p.im * p.im));
             max_rel = rel > max_rel ? rel : max_rel;
         }
-        if (!(max_rel > 4e-16)) break;
+        // converged: the corrections are at the rounding floor of the Horner evaluation
+        // (they stop shrinking once they are tiny) -- or vanish altogether
+        if (!(max_rel > 4e-16) || (max_rel < 1e-11 && max_rel > 0.25 * prev_rel)) break;
+        prev_rel = max_rel;
     }
 #pragma unroll
     for (int i = 0; i < 10; i++) roots_out[i] = roots[i];
 }
 
-// EMEstimatorCallback::runKernel for five normalised correspondences; up to ten matrices.
-__device__ int five_point(const double2* s1, const double2* s2, double* ematrix) {
-    double q[45];
+// EMEstimatorCallback::runKernel for five normalised correspondences; up to ten matrices
+// (9 doubles each) to `ematrix`.  `work` is this sample's column of the workgroup's LDS.
+__device__ int five_point(const double2* s1, const double2* s2, Lds work, double* ematrix) {
+    const Lds q = work, ee = q.at(kSolveQ), lin = ee.at(kSolveEe), lam = lin.at(kSolveLin), a = lam.at(kSolveLam),
+              b = a.at(kSolveA), pz = b.at(kSolveB), tmp = pz.at(kSolvePz);
     for (int i = 0; i < 5; ++i) {
         const double x1 = s1[i].x, y1 = s1[i].y, x2 = s2[i].x, y2 = s2[i].y;
-        double* r = q + 9 * i;
+        const Lds r = q.at(9 * i);
         r[0] = x2 * x1;
         r[1] = x2 * y1;
         r[2] = x2;
@@ -248,6 +269,7 @@ __device__ int five_point(const double2* s1, const double2* s2, double* ematrix)
     // null space: Gauss-Jordan with complete pivoting
     int col_of[5];
     unsigned used = 0;
+#pragma unroll
     for (int k = 0; k < 5; ++k) {
         int pr = -1, pc = -1;
         double best = 0;
@@ -275,95 +297,91 @@ __device__ int five_point(const double2* s1, const double2* s2, double* ematrix)
             for (int c = 0; c < 9; ++c) q[r * 9 + c] -= m * q[k * 9 + c];
         }
     }
-    double ee[4][9];  // E = x ee[0] + y ee[1] + z ee[2] + ee[3]
+    // ee[v * 9 + k]: E = x ee[0] + y ee[1] + z ee[2] + ee[3]
     {
         int nf = 0;
         for (int c = 0; c < 9 && nf < 4; ++c) {
             if ((used >> c) & 1u) continue;
-            double* f = ee[nf++];
+            const Lds f = ee.at(9 * nf++);
             for (int j = 0; j < 9; ++j) f[j] = 0;
             f[c] = 1.0;
+#pragma unroll
             for (int k = 0; k < 5; ++k) f[col_of[k]] = -q[k * 9 + c];
         }
         for (int v = 0; v < 4; ++v) {  // modified Gram-Schmidt
             for (int u = 0; u < v; ++u) {
                 double dot = 0;
-                for (int j = 0; j < 9; ++j) dot += ee[v][j] * ee[u][j];
-                for (int j = 0; j < 9; ++j) ee[v][j] -= dot * ee[u][j];
+                for (int j = 0; j < 9; ++j) dot += ee[v * 9 + j] * ee[u * 9 + j];
+                for (int j = 0; j < 9; ++j) ee[v * 9 + j] -= dot * ee[u * 9 + j];
             }
             double n2 = 0;
-            for (int j = 0; j < 9; ++j) n2 += ee[v][j] * ee[v][j];
+            for (int j = 0; j < 9; ++j) n2 += ee[v * 9 + j] * ee[v * 9 + j];
             if (!(n2 > 0)) return 0;
             const double inv = 1.0 / sqrt(n2);
-            for (int j = 0; j < 9; ++j) ee[v][j] *= inv;
+            for (int j = 0; j < 9; ++j) ee[v * 9 + j] *= inv;
         }
     }
-    // entries of E as linear polynomials: lin[r][c] = (x, y, z, 1) coefficients
-    double lin[9][4];
+    // entries of E as linear polynomials: lin[k * 4 + v] = (x, y, z, 1) coefficients of entry k
     for (int k = 0; k < 9; ++k)
-        for (int v = 0; v < 4; ++v) lin[k][v] = ee[v][k];
+        for (int v = 0; v < 4; ++v) lin[k * 4 + v] = ee[v * 9 + k];
+    const Lds l1 = tmp, t20 = tmp.at(20);  // two scratch polynomials
     // Lambda = E E^T - tr(E E^T) / 2 I, quadratic entries held as full 20-vectors
-    double lam[9][20];
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) {
-            double* o = lam[3 * r + c];
+            const Lds o = lam.at(20 * (3 * r + c));
             for (int m = 0; m < 20; ++m) o[m] = 0;
             for (int k = 0; k < 3; ++k) {
-                double l1[20];
                 for (int m = 0; m < 20; ++m) l1[m] = 0;
-                for (int v = 0; v < 4; ++v) l1[kMono.lin[v]] = lin[3 * r + k][v];
-                mul_linear_acc(l1, lin[3 * c + k], 1.0, o);
+                for (int v = 0; v < 4; ++v) l1[kMono.lin[v]] = lin[(3 * r + k) * 4 + v];
+                mul_linear_acc(l1, lin.at((3 * c + k) * 4), 1.0, o);
             }
         }
     for (int m = 0; m < 20; ++m) {
-        const double half = 0.5 * (lam[0][m] + lam[4][m] + lam[8][m]);
-        lam[0][m] -= half;
-        lam[4][m] -= half;
-        lam[8][m] -= half;
+        const double half = 0.5 * (lam[m] + lam[80 + m] + lam[160 + m]);
+        lam[m] -= half;
+        lam[80 + m] -= half;
+        lam[160 + m] -= half;
     }
-    double a[10][20];
-    for (int r = 0; r < 10; ++r)
-        for (int m = 0; m < 20; ++m) a[r][m] = 0;
+    for (int r = 0; r < 200; ++r) a[r] = 0;
     {
         const int8_t perm[6][4] = {{0, 1, 2, 1}, {1, 2, 0, 1}, {2, 0, 1, 1}, {0, 2, 1, -1}, {1, 0, 2, -1}, {2, 1, 0, -1}};
         for (int p = 0; p < 6; ++p) {
-            double l1[20], t[20];
-            for (int m = 0; m < 20; ++m) l1[m] = t[m] = 0;
-            for (int v = 0; v < 4; ++v) l1[kMono.lin[v]] = lin[perm[p][0]][v];
-            mul_linear_acc(l1, lin[3 + perm[p][1]], 1.0, t);
-            mul_linear_acc(t, lin[6 + perm[p][2]], (double)perm[p][3], a[0]);
+            for (int m = 0; m < 20; ++m) l1[m] = t20[m] = 0;
+            for (int v = 0; v < 4; ++v) l1[kMono.lin[v]] = lin[perm[p][0] * 4 + v];
+            mul_linear_acc(l1, lin.at((3 + perm[p][1]) * 4), 1.0, t20);
+            mul_linear_acc(t20, lin.at((6 + perm[p][2]) * 4), (double)perm[p][3], a);
         }
     }
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c)
-            for (int k = 0; k < 3; ++k) mul_linear_acc(lam[3 * r + k], lin[3 * k + c], 1.0, a[1 + 3 * r + c]);
+            for (int k = 0; k < 3; ++k)
+                mul_linear_acc(lam.at(20 * (3 * r + k)), lin.at((3 * k + c) * 4), 1.0, a.at(20 * (1 + 3 * r + c)));
     // A[:, :10]^-1 A[:, 10:]
     for (int k = 0; k < 10; ++k) {
         int pr = k;
         for (int r = k + 1; r < 10; ++r)
-            if (fabs(a[r][k]) > fabs(a[pr][k])) pr = r;
-        if (a[pr][k] == 0) return 0;
+            if (fabs(a[r * 20 + k]) > fabs(a[pr * 20 + k])) pr = r;
+        if (a[pr * 20 + k] == 0) return 0;
         if (pr != k)
             for (int c = 0; c < 20; ++c) {
-                const double t = a[k][c];
-                a[k][c] = a[pr][c];
-                a[pr][c] = t;
+                const double t = a[k * 20 + c];
+                a[k * 20 + c] = a[pr * 20 + c];
+                a[pr * 20 + c] = t;
             }
-        const double inv = 1.0 / a[k][k];
-        for (int c = 0; c < 20; ++c) a[k][c] *= inv;
+        const double inv = 1.0 / a[k * 20 + k];
+        for (int c = 0; c < 20; ++c) a[k * 20 + c] *= inv;
         for (int r = 0; r < 10; ++r) {
             if (r == k) continue;
-            const double m = a[r][k];
+            const double m = a[r * 20 + k];
             if (m == 0) continue;
-            for (int c = 0; c < 20; ++c) a[r][c] -= m * a[k][c];
+            for (int c = 0; c < 20; ++c) a[r * 20 + c] -= m * a[k * 20 + c];
         }
     }
-    // B(z): columns x z^3, x z^2, x z, x | y z^3, y z^2, y z, y | z^4, z^3, z^2, z, 1
-    double b[3][13];
+    // B(z): b[i * 13 + k], columns x z^3, x z^2, x z, x | y z^3, y z^2, y z, y | z^4, z^3, z^2, z, 1
     for (int i = 0; i < 3; ++i) {
-        const double* r1 = a[4 + 2 * i] + 10;
-        const double* r2 = a[5 + 2 * i] + 10;
-        double row1[13], row2[13];
+        const Lds r1 = a.at((4 + 2 * i) * 20 + 10);
+        const Lds r2 = a.at((5 + 2 * i) * 20 + 10);
+        const Lds row1 = tmp, row2 = tmp.at(13);
         for (int k = 0; k < 13; ++k) row1[k] = row2[k] = 0;
         for (int k = 0; k < 3; ++k) {
             row1[1 + k] = r1[k];
@@ -375,45 +393,54 @@ __device__ int five_point(const double2* s1, const double2* s2, double* ematrix)
             row1[9 + k] = r1[6 + k];
             row2[8 + k] = r2[6 + k];
         }
-        for (int k = 0; k < 13; ++k) b[i][k] = row1[k] - row2[k];
+        for (int k = 0; k < 13; ++k) b[i * 13 + k] = row1[k] - row2[k];
     }
     double c[11];
+#pragma unroll
     for (int k = 0; k < 11; ++k) c[k] = 0;
     {
-        double pz[3][3][5];
+        // pz[(i * 3 + j) * 5 + k]: entry (i, j) of B as a polynomial in z, lowest degree first
         for (int i = 0; i < 3; ++i) {
-            for (int k = 0; k < 5; ++k) pz[i][0][k] = pz[i][1][k] = pz[i][2][k] = 0;
+            for (int k = 0; k < 5; ++k) pz[(i * 3) * 5 + k] = pz[(i * 3 + 1) * 5 + k] = pz[(i * 3 + 2) * 5 + k] = 0;
             for (int k = 0; k < 4; ++k) {
-                pz[i][0][k] = b[i][3 - k];
-                pz[i][1][k] = b[i][7 - k];
+                pz[(i * 3) * 5 + k] = b[i * 13 + 3 - k];
+                pz[(i * 3 + 1) * 5 + k] = b[i * 13 + 7 - k];
             }
-            for (int k = 0; k < 5; ++k) pz[i][2][k] = b[i][12 - k];
+            for (int k = 0; k < 5; ++k) pz[(i * 3 + 2) * 5 + k] = b[i * 13 + 12 - k];
         }
         const int8_t perm[6][4] = {{0, 1, 2, 1}, {1, 2, 0, 1}, {2, 0, 1, 1}, {0, 2, 1, -1}, {1, 0, 2, -1}, {2, 1, 0, -1}};
         for (int p = 0; p < 6; ++p) {
             double t[9];
+#pragma unroll
             for (int u = 0; u < 9; ++u) t[u] = 0;
+#pragma unroll
             for (int u = 0; u < 5; ++u)
-                for (int v = 0; v < 5; ++v) t[u + v] += pz[0][perm[p][0]][u] * pz[1][perm[p][1]][v];
+#pragma unroll
+                for (int v = 0; v < 5; ++v) t[u + v] += pz[perm[p][0] * 5 + u] * pz[(3 + perm[p][1]) * 5 + v];
+#pragma unroll
             for (int u = 0; u < 9; ++u)
+#pragma unroll
                 for (int v = 0; v < 5; ++v)
-                    if (u + v <= 10) c[u + v] += perm[p][3] * t[u] * pz[2][perm[p][2]][v];
+                    if (u + v <= 10) c[u + v] += perm[p][3] * t[u] * pz[(6 + perm[p][2]) * 5 + v];
         }
     }
     Cplx roots[10];
     solve_poly10(c, roots);
     int count = 0;
+#pragma unroll
     for (int i = 0; i < 10; ++i) {
         if (fabs(roots[i].im) > 1e-10) continue;
         const double z1 = roots[i].re, z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
         double bz[3][3];
+#pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const double* br = b[j];
+            const Lds br = b.at(13 * j);
             bz[j][0] = br[0] * z3 + br[1] * z2 + br[2] * z1 + br[3];
             bz[j][1] = br[4] * z3 + br[5] * z2 + br[6] * z1 + br[7];
             bz[j][2] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
         }
         double best[3] = {0, 0, 0}, best_n2 = -1;
+#pragma unroll
         for (int u = 0; u < 3; ++u) {
             const double* r0 = bz[u];
             const double* r1 = bz[(u + 1) % 3];
@@ -425,14 +452,16 @@ __device__ int five_point(const double2* s1, const double2* s2, double* ematrix)
         if (!(best_n2 > 0)) continue;
         if (fabs(best[2] * (1.0 / sqrt(best_n2))) < 1e-10) continue;
         const double x = best[0] / best[2], y = best[1] / best[2];
-        double* out = ematrix + 9 * count;
+        double e9[9];
         double n2 = 0;
+#pragma unroll
         for (int k = 0; k < 9; ++k) {
-            out[k] = ee[0][k] * x + ee[1][k] * y + ee[2][k] * z1 + ee[3][k];
-            n2 += out[k] * out[k];
+            e9[k] = ee[k] * x + ee[9 + k] * y + ee[18 + k] * z1 + ee[27 + k];
+            n2 += e9[k] * e9[k];
         }
         const double inv = 1.0 / sqrt(n2);
-        for (int k = 0; k < 9; ++k) out[k] *= inv;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ematrix[9 * count + k] = e9[k] * inv;
         count++;
     }
     return count;
@@ -634,26 +663,26 @@ __device__ __forceinline__ float sampson(const double (&E)[9], double2 p1, doubl
     return (float)(x2tex1 * x2tex1 / (a + b + c + d));
 }
 
-// One lane per (point set, live iteration of the round): the 5-point solve; for LMedS also
-// the median error of each matrix (point sets are small there or the caller asked for it).
-__global__ __launch_bounds__(64) void em_solve_kernel(EmArgs a) {
+// One lane per (point set, live iteration of the round): the 5-point solve, sixteen to a
+// workgroup (the LDS their work arrays need).
+__global__ __launch_bounds__(kSolveLanes) void em_solve_kernel(EmArgs a) {
+    __shared__ double s_work[kSolveDoubles * kSolveLanes];
     const int p = blockIdx.y;
     const int count = problem_count(a, p);
     const int end = live_end(a, p, count);
     const double2* m1 = a.m1 + (size_t)p * a.stride;
     const double2* m2 = a.m2 + (size_t)p * a.stride;
-    for (int it = a.lo + blockIdx.x * 64 + threadIdx.x; it < end; it += gridDim.x * 64) {
+    const Lds work = {s_work + threadIdx.x};
+    for (int it = a.lo + blockIdx.x * kSolveLanes + threadIdx.x; it < end; it += gridDim.x * kSolveLanes) {
         const size_t slot = (size_t)p * a.max_iters + it;
         double2 s1[5], s2[5];
+#pragma unroll
         for (int k = 0; k < 5; ++k) {
             const int j = count == 5 ? k : a.subsets[slot * 5 + k];
             s1[k] = m1[j];
             s2[k] = m2[j];
         }
-        double models[kMaxModels * 9];
-        const int n = five_point(s1, s2, models);
-        a.n_models[slot] = n;
-        for (int k = 0; k < n * 9; ++k) a.models[slot * kMaxModels * 9 + k] = models[k];
+        a.n_models[slot] = five_point(s1, s2, work, a.models + slot * kMaxModels * 9);
         for (int m = 0; m < kMaxModels; ++m) a.scores[slot * kMaxModels + m] = 0;
     }
 }
@@ -889,7 +918,8 @@ int sfm_find_essential_dev(sfm_ctx* ctx, const float* d_pts1, const float* d_pts
         }
         {
             KernelTimer timer(ctx, KID_EM_SOLVE);
-            hipLaunchKernelGGL(em_solve_kernel, dim3(std::min((hi - lo + 63) / 64, 16), n_problems), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(em_solve_kernel, dim3(std::min((hi - lo + kSolveLanes - 1) / kSolveLanes, 64), n_problems),
+                               dim3(kSolveLanes), 0, s, a);
             SFM_HIP_CHECK(ctx, hipGetLastError());
         }
         {
