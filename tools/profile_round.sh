@@ -22,7 +22,7 @@ run() { # name, limit, args...
 }
 
 BENCH="python3 $ROOT/bench.py --no-cpu-baseline"
-for wl in framepair c3 c4 f1 f2 f3; do
+for wl in framepair c3 c4 f1 f2 f3 vo; do
     run stats_$wl 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -o $wl \
         -- $BENCH --workload $wl --steps 5 --warmup 2
 done
