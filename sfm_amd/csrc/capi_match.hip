@@ -47,30 +47,52 @@ bool is_packed(const void* p, size_t stride, int d, int row_words) {
     return d == row_words * 4 && stride == (size_t)d && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
 }
 
-// Whether the one-pass pair kernel handles this row width.  SFM_PAIR_KERNEL=0 selects the
-// two-direction path for every width (a debugging and measurement aid).
-// The pair kernel's unit of work is coarse (one wave: 256 rows of prev against a batch of
-// 256 rows of curr), so it needs enough of them to occupy the chip; a single small pair is
-// faster through the finely split single-direction kernel.
-bool use_pair_kernel(const sfm_ctx* ctx, int row_words, int rows_max, int n_pairs) {
-    static const int mode = [] {
-        const char* e = getenv("SFM_PAIR_KERNEL");
-        return e ? atoi(e) : -1;  // 0: never, 1: whenever the width allows, unset: by size
-    }();
-    if (mode == 0 || hamming_pair_block_rows(row_words) == 0) return false;
-    if (mode == 1) return true;
+// Which kernel computes the two 2-NN searches of every pair.
+enum HammingPath {
+    kPathKnn2 = 0,   // hamming_knn2_kernel, once per direction: any width, finely split
+    kPathPair = 1,   // hamming_pair_kernel: both directions from one pass of xor / popcount
+    kPathMfma = 2    // hamming_mfma_kernel: signed-byte contraction on the matrix cores
+};
+// SFM_PAIR_KERNEL=0/1/2 forces a path wherever the row width allows it (a debugging and
+// measurement aid); unset, the size decides.  The matrix kernel's workgroup owns 512 queries
+// and at least two 64-row train tiles, the pair kernel's wave 256 rows of prev against 256 of
+// curr: both need enough such units to occupy the chip, and a single small pair is faster
+// through the finely split single-direction kernel.
+HammingPath hamming_path(const sfm_ctx* ctx, int row_words, int rows_max, int n_pairs) {
+    const char* e = getenv("SFM_PAIR_KERNEL");  // read per call: tests switch it in-process
+    const int mode = e && *e ? atoi(e) : -1;
+    const bool pair_ok = hamming_pair_block_rows(row_words) != 0;
+    const bool mfma_ok = hamming_mfma_q_per_block(row_words) != 0 && rows_max >= 128;
+    if (mode == 0) return kPathKnn2;
+    if (mode == 1) return pair_ok ? kPathPair : kPathKnn2;
+    if (mode == 2) return mfma_ok ? kPathMfma : kPathKnn2;
     const long tiles = (rows_max + 255) / 256;
-    return (long)n_pairs * tiles * tiles >= 3L * ctx->num_cus;
+    if (mfma_ok && (long)n_pairs * tiles * tiles >= ctx->num_cus / 4) return kPathMfma;
+    if (pair_ok && (long)n_pairs * tiles * tiles >= 3L * ctx->num_cus) return kPathPair;
+    return kPathKnn2;
 }
 
 // Hamming robust matching over frames already packed to plan.row_words words per
-// row.  Workspace is carved from `c`.
-int hamming_pairs_packed(sfm_ctx* ctx, const KnnPlan& plan, const void* packed, size_t frame_stride,
-                         int rows_uniform, const int32_t* d_counts, const int32_t* d_pairs,
-                         int n_pairs, float ratio, sfm_dmatch* d_matches, int cap,
-                         int32_t* d_match_counts, Carver& c) {
+// row (and, for the matrix path, their signed-byte form `expanded`).  Workspace is carved
+// from `c`.
+int hamming_pairs_packed(sfm_ctx* ctx, const KnnPlan& plan, HammingPath path, const void* packed,
+                         size_t frame_stride, const void* expanded, int rows_uniform,
+                         const int32_t* d_counts, const int32_t* d_pairs, int n_pairs, float ratio,
+                         sfm_dmatch* d_matches, int cap, int32_t* d_match_counts, Carver& c) {
     const size_t nprob = 2 * (size_t)n_pairs;
-    if (use_pair_kernel(ctx, plan.row_words, plan.rows_max, n_pairs)) {
+    if (path == kPathMfma) {
+        const MfmaPlan mp = make_mfma_plan(ctx, plan.row_words, plan.rows_max, (int)nprob);
+        uint32_t* keys = c.take<uint32_t>(nprob * mp.splits * mp.rows_max * 2);
+        int32_t* best = c.take<int32_t>(nprob * plan.rows_max);
+        float* best_dist = c.take<float>(nprob * plan.rows_max);
+        SFM_RETURN_IF(launch_hamming_mfma(ctx, mp, expanded, rows_uniform, d_counts, d_pairs, n_pairs,
+                                          keys));
+        KnnPlan merged = plan;
+        merged.splits = mp.splits;
+        return launch_ratio_cross(ctx, merged, keys, d_counts, rows_uniform, rows_uniform, d_pairs,
+                                  n_pairs, ratio, best, best_dist, d_matches, cap, d_match_counts);
+    }
+    if (path == kPathPair) {
         const PairPlan pp = make_pair_plan(ctx, plan.row_words, plan.rows_max, n_pairs);
         uint32_t* keys_row = c.take<uint32_t>((size_t)n_pairs * pp.splits * pp.rows_max * 2);
         uint32_t* keys_col = c.take<uint32_t>((size_t)n_pairs * pp.qblocks * pp.rows_max * 2);
@@ -97,10 +119,13 @@ int hamming_pairs_packed(sfm_ctx* ctx, const KnnPlan& plan, const void* packed, 
                               n_pairs, ratio, best, best_dist, d_matches, cap, d_match_counts);
 }
 
-size_t hamming_pairs_bytes(const sfm_ctx* ctx, const KnnPlan& plan, int n_pairs) {
+size_t hamming_pairs_bytes(const sfm_ctx* ctx, const KnnPlan& plan, HammingPath path, int n_pairs) {
     Carver c(nullptr);
     const size_t nprob = 2 * (size_t)n_pairs;
-    if (use_pair_kernel(ctx, plan.row_words, plan.rows_max, n_pairs)) {
+    if (path == kPathMfma) {
+        const MfmaPlan mp = make_mfma_plan(ctx, plan.row_words, plan.rows_max, (int)nprob);
+        c.take<uint32_t>(nprob * mp.splits * mp.rows_max * 2);
+    } else if (path == kPathPair) {
         const PairPlan pp = make_pair_plan(ctx, plan.row_words, plan.rows_max, n_pairs);
         c.take<uint32_t>((size_t)n_pairs * pp.splits * pp.rows_max * 2);
         c.take<uint32_t>((size_t)n_pairs * pp.qblocks * pp.rows_max * 2);
@@ -254,8 +279,12 @@ size_t sfm_match_pairs_workspace(int norm, int n_frames, int rows_per_frame, int
     sfm_ctx fake;
     KnnPlan plan = make_knn_plan(&fake, norm, d, rows_per_frame, rows_per_frame, 2 * chunk);
     const bool packed = d == plan.row_words * 4;
-    return hamming_pairs_bytes(&fake, plan, chunk) +
-           (packed ? 0 : align_up((size_t)n_frames * rows_per_frame * plan.row_words * 4, 256));
+    const HammingPath path = hamming_path(&fake, plan.row_words, plan.rows_max, chunk);
+    return hamming_pairs_bytes(&fake, plan, path, chunk) +
+           (packed ? 0 : align_up((size_t)n_frames * rows_per_frame * plan.row_words * 4, 256)) +
+           (path == kPathMfma
+                ? align_up((size_t)n_frames * hamming_mfma_frame_bytes(plan.row_words, rows_per_frame), 256)
+                : 0);
 }
 
 int sfm_match_pairs_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames,
@@ -281,11 +310,15 @@ int sfm_match_pairs_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames
     const size_t row_bytes = (size_t)plan.row_words * 4;
     const bool packed = d == plan.row_words * 4 && (frame_stride & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(d_desc) & 15) == 0;
+    const HammingPath path = hamming_path(ctx, plan.row_words, plan.rows_max, chunk);
+    const size_t expanded_bytes =
+        path == kPathMfma ? (size_t)n_frames * hamming_mfma_frame_bytes(plan.row_words, rows_per_frame) : 0;
     Carver sz(nullptr);
     if (!packed) sz.take<uint8_t>((size_t)n_frames * rows_per_frame * row_bytes);
+    if (expanded_bytes) sz.take<uint8_t>(expanded_bytes);
     const size_t fixed = sz.total();
     void* ws;
-    SFM_RETURN_IF(workspace(ctx, fixed + hamming_pairs_bytes(ctx, plan, chunk), &ws));
+    SFM_RETURN_IF(workspace(ctx, fixed + hamming_pairs_bytes(ctx, plan, path, chunk), &ws));
     Carver c(ws);
     const void* base = d_desc;
     size_t fstride = frame_stride;
@@ -297,12 +330,18 @@ int sfm_match_pairs_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames
                                     rows_per_frame, (size_t)d, d, p + f * fstride, plan.row_words));
         base = p;
     }
+    void* expanded = nullptr;
+    if (expanded_bytes) {
+        expanded = c.take<uint8_t>(expanded_bytes);
+        SFM_RETURN_IF(launch_hamming_expand(ctx, base, fstride, plan.row_words, rows_per_frame,
+                                            n_frames, expanded));
+    }
     const size_t carve_mark = c.off;
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
         const int np = std::min(chunk, n_pairs - p0);
         c.off = carve_mark;
-        SFM_RETURN_IF(hamming_pairs_packed(ctx, plan, base, fstride, rows_per_frame, d_counts,
-                                           d_pairs + 2 * (size_t)p0, np, ratio,
+        SFM_RETURN_IF(hamming_pairs_packed(ctx, plan, path, base, fstride, expanded, rows_per_frame,
+                                           d_counts, d_pairs + 2 * (size_t)p0, np, ratio,
                                            d_matches + (size_t)p0 * cap, cap, d_match_counts + p0,
                                            c));
     }

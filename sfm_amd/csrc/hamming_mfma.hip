@@ -1,0 +1,363 @@
+// Hamming 2-nearest-neighbour search of many (query frame, train frame) problems on the
+// integer matrix cores of gfx950.
+//
+// Replaces the two cv::BFMatcher(NORM_HAMMING)::knnMatch(.., 2) calls of
+// DescriptorMatcher::findRobustMatches (Source Files/feature_processing.cpp:148-149) when a
+// launch holds enough of them to fill the chip.
+//
+// popcount(q ^ t) over B bits is a contraction: with every bit written as a signed byte,
+// s(0) = +64 and s(1) = -64, a train row as s(t) and a query row as -s(q),
+//     sum_k s(t_k) * (-s(q_k)) = 4096 * (#differing - #equal) = 8192 * h - 4096 * B.
+// v_mfma_i32_32x32x32_i8 forms it exactly in int32.  The accumulator of train row r starts at
+// 4096 * B + (r - first row of the workgroup's train range), so when the k loop ends it IS the
+// ranking key  8192 * h + local train index  (a workgroup's range holds at most 8192 rows): no
+// instruction builds keys.  Train tiles are the A operand (rows), the queries the B operand
+// (columns): each lane's 16 accumulator registers are 16 train rows of ONE query, so the
+// running best-two of that query stay in two of the lane's registers and take one v_med3_u32
+// and one v_min_u32 per distance.  The minimum of (distance, index) keys does not depend on
+// the visiting order, so the neighbours, ties included, are those of the scalar kernels
+// (hamming_knn2.hip, hamming_pair.hip).
+//
+// The signed-byte rows are written once per frame by hamming_expand_kernel; a workgroup keeps
+// its 512 queries (8 waves x 64) in registers for its whole life and streams 64-row train
+// tiles global -> LDS (XOR-swizzled so that the 16-byte fragment reads are conflict-free),
+// double-buffered.  Two accumulator sets alternate, one per 32-row half of a tile: while the
+// matrix pipe works on one half the vector ALU folds the previous one into the best-two lists,
+// a slice after every k step.
+#include "sfm_internal.h"
+
+namespace sfm {
+
+namespace {
+
+typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef int intx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int kTileRows = 64;        // train rows per LDS tile: two 32-row MFMA tiles
+constexpr int kLocalBits = 13;       // a workgroup's train range holds at most 2^13 rows
+constexpr int kIdxBits = 18;         // index bits of the keys the merge kernels read
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+constexpr uint32_t kEmpty = 0x7FFFFFFFu;   // tracker start, above every real accumulator
+constexpr int kMasked = 0x40000000;        // accumulator start of a row past the range
+constexpr uint32_t kRealLimit = 0x20000000u;
+
+struct MfmaArgs {
+    const uint8_t* rows;     // signed-byte frames: frame f at rows + f * frame_bytes
+    size_t frame_bytes;
+    const int32_t* counts;   // per-frame row counts or nullptr
+    int rows_uniform;
+    const int32_t* pairs;    // [n_pairs][2]; problem 2p is (a -> b), 2p + 1 is (b -> a)
+    int n_problems;
+    int qtiles, splits;
+    int rows_max;
+    int grouped;
+    uint2* keys;             // [problem][split][rows_max]
+};
+
+// Median of three; the compiler turns this form into one v_med3_u32.  (Not inline asm: the
+// instruction scheduler must see a vector ALU instruction to place it between the MFMAs.)
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
+    return max(min(a, b), min(max(a, b), c));
+}
+
+__device__ __forceinline__ void top2(uint32_t& m1, uint32_t& m2, uint32_t key) {
+    m2 = med3_u32(m1, m2, key);
+    m1 = min(m1, key);
+}
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lptr, 16, 0, 0);
+}
+
+// One thread per 16 output bytes: 16 bits of a packed row become 16 signed bytes,
+// bit 0 -> +64 (0x40), bit 1 -> -64 (0xC0); byte b of a row is bit b of the descriptor.
+__global__ __launch_bounds__(256) void hamming_expand_kernel(const uint32_t* __restrict__ packed,
+                                                             size_t frame_words, int row_words,
+                                                             int rows, int n_frames,
+                                                             uint4* __restrict__ out) {
+    const size_t per_frame = (size_t)rows * row_words * 2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_frame * n_frames) return;
+    const size_t f = i / per_frame, r = i % per_frame;
+    const uint32_t word = packed[f * frame_words + (r >> 1)];
+    const uint32_t bits = (word >> (16 * (r & 1))) & 0xFFFFu;
+    uint32_t d[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t nib = (bits >> (4 * q)) & 0xFu;
+        const uint32_t spread = (nib * 0x00204081u) & 0x01010101u;  // bit j -> byte j
+        d[q] = 0x40404040u | (spread << 7);
+    }
+    out[i] = make_uint4(d[0], d[1], d[2], d[3]);
+}
+
+// W: 32-bit words per packed row (the contraction length is 32 W), NT: 32-query tiles per wave.
+template <int W, int NT>
+__global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
+    constexpr int kRowBytes = 32 * W;
+    constexpr int kCpr = kRowBytes / 16;                 // 16-byte chunks per row
+    constexpr int kSwz = kCpr < 16 ? kCpr - 1 : 15;
+    constexpr int kTileBytes = kTileRows * kRowBytes;
+    constexpr int kStagePerWave = kCpr / kWaves;         // 1 KiB wave-instructions per wave and tile
+    static_assert(kCpr % kWaves == 0, "a tile must split evenly over the waves");
+    constexpr int kQPerWave = 32 * NT;
+    constexpr int kQPerBlock = kWaves * kQPerWave;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kTileBytes];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int per_problem = a.qtiles * a.splits;
+    int problem, inner;
+    if (a.grouped) {  // eight problems per XCD label: a problem's train frame stays in one L2
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        problem = (slot / per_problem) * 8 + xcd;
+        inner = slot % per_problem;
+    } else {
+        problem = blockIdx.x / per_problem;
+        inner = blockIdx.x % per_problem;
+    }
+    if (problem >= a.n_problems) return;
+    const int pair = problem >> 1, dir = problem & 1;
+    const int fa = a.pairs[2 * pair], fb = a.pairs[2 * pair + 1];
+    const int qf = dir ? fb : fa, tf = dir ? fa : fb;
+    const int nq = a.counts ? a.counts[qf] : a.rows_uniform;
+    const int nt = a.counts ? a.counts[tf] : a.rows_uniform;
+    const int qtile = inner / a.splits, split = inner % a.splits;
+    const int q0 = qtile * kQPerBlock;
+    if (q0 >= nq) return;  // the merge reads only rows below nq
+    const uint8_t* qrows = a.rows + (size_t)qf * a.frame_bytes;
+    const uint8_t* trows = a.rows + (size_t)tf * a.frame_bytes;
+
+    // B operand: the negated signed bytes of this lane's queries, resident for the whole kernel.
+    // breg[n][m] holds bits 32m + 16lh .. + 15 of query q0 + wave * kQPerWave + 32n + li.
+    intx4 breg[NT][W];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        int qi = q0 + wave * kQPerWave + 32 * n + li;
+        qi = qi < nq ? qi : nq - 1;
+        const intx4* src = reinterpret_cast<const intx4*>(qrows + (size_t)qi * kRowBytes);
+#pragma unroll
+        for (int m = 0; m < W; ++m) {
+            const intx4 v = src[2 * m + lh];
+            breg[n][m] = v ^ (int)0x80808080;  // +-64 -> -+64
+        }
+    }
+    uint32_t m1[NT], m2[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) m1[n] = m2[n] = kEmpty;
+
+    // this workgroup's train range: whole tiles, at most 2^kLocalBits rows
+    const int tiles_total = (nt + kTileRows - 1) / kTileRows;
+    const int tiles_per_split = (tiles_total + a.splits - 1) / a.splits;
+    const int t_begin = split * tiles_per_split * kTileRows;
+    const int t_end = min(nt, t_begin + tiles_per_split * kTileRows);
+    const int ntiles = t_end > t_begin ? (t_end - t_begin + kTileRows - 1) / kTileRows : 0;
+
+    // global -> LDS copy of one tile: LDS position p (16-byte chunks, linear) holds chunk
+    // (p % kCpr) ^ (row & kSwz) of row p / kCpr; each wave instruction fills 64 positions.
+    auto stage = [&](int k, int buf) {
+        const int tbase = t_begin + k * kTileRows;
+        uint8_t* dst = lds + buf * kTileBytes;
+#pragma unroll
+        for (int it = 0; it < kStagePerWave; ++it) {
+            const int instr = wave * kStagePerWave + it;
+            const int p = instr * 64 + lane;
+            const int row = p / kCpr, cpos = p % kCpr;
+            const int c = cpos ^ (row & kSwz);
+            int trow = tbase + row;
+            trow = trow < nt ? trow : nt - 1;  // rows past the end are masked below
+            glds16(trows + (size_t)trow * kRowBytes + c * 16, dst + instr * 1024);
+        }
+    };
+
+    if (ntiles > 0) stage(0, 0);
+
+    // accumulator start: register r of a 32-row half tile is its train row 8(r>>2) + 4lh + (r&3);
+    // it starts at 4096 * bits + the row's index in the workgroup's range
+    intx16 init;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) init[r] = 4096 * kRowBytes + 8 * (r >> 2) + 4 * lh + (r & 3);
+    __syncthreads();
+
+    // Two accumulator sets, one per half of a tile.  While the matrix pipe accumulates one half
+    // tile into one set, the vector ALU folds the other set (the previous half tile) into the
+    // best-two lists, a slice of it after every k step, so the fold hides behind the MFMAs.
+    constexpr int kGroups = NT * 4;  // groups of 4 accumulator registers per set
+    intx16 acc0[NT], acc1[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[n][r] = acc1[n][r] = kMasked;
+
+    auto fold_group = [&](const intx16 (&acc)[NT], int gi) {
+        const int n = gi / 4, gq = gi % 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) top2(m1[n], m2[n], (uint32_t)acc[n][4 * gq + r]);
+    };
+
+    const int left = t_end - t_begin;
+    auto mask_init = [&]() {  // the last tile may hold rows past the range
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if ((init[r] & ((1 << kLocalBits) - 1)) >= left) init[r] = kMasked;
+    };
+    auto half_step = [&](intx16 (&accC)[NT], const intx16 (&accF)[NT], const uint8_t* tile, int mt) {
+        const int row = 32 * mt + li;
+        const uint8_t* rowp = tile + row * kRowBytes;
+        const int swz = row & kSwz;
+        intx4 av = *reinterpret_cast<const intx4*>(rowp + (lh ^ swz) * 16), av_next;
+#pragma unroll
+        for (int m = 0; m < W; ++m) {
+            if (m + 1 < W)
+                av_next = *reinterpret_cast<const intx4*>(rowp + ((2 * (m + 1) + lh) ^ swz) * 16);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                accC[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, breg[n][m],
+                                                                m == 0 ? init : accC[n], 0, 0, 0);
+            // The fold of the other set starts one k step late (that set's last MFMAs were
+            // issued just before this half tile; the first k step advances the start values
+            // to the next half tile instead) and is spread over the remaining k steps.
+            if (m == 0) {
+                init += 32;
+            } else {
+#pragma unroll
+                for (int gi = ((m - 1) * kGroups) / (W - 1); gi < (m * kGroups) / (W - 1); ++gi)
+                    fold_group(accF, gi);
+            }
+            av = av_next;
+            // keep every k step's MFMAs and its share of the fold together: the compiler
+            // otherwise gathers the whole fold in front of the MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    for (int k = 0; k + 1 < ntiles; ++k) {
+        const int buf = k & 1;
+        stage(k + 1, buf ^ 1);
+        const uint8_t* tile = lds + buf * kTileBytes;
+        half_step(acc0, acc1, tile, 0);
+        half_step(acc1, acc0, tile, 1);
+        __syncthreads();
+    }
+    if (ntiles > 0) {
+        const uint8_t* tile = lds + ((ntiles - 1) & 1) * kTileBytes;
+        mask_init();
+        half_step(acc0, acc1, tile, 0);
+        mask_init();
+        half_step(acc1, acc0, tile, 1);
+    }
+#pragma unroll
+    for (int gi = 0; gi < kGroups; ++gi) fold_group(acc1, gi);
+
+    // accumulator -> (distance << 18 | train index); the two lane halves saw different rows
+    auto to_key = [&](uint32_t v) {
+        const uint32_t h = v >> kLocalBits, local = v & ((1u << kLocalBits) - 1);
+        return v < kRealLimit ? (h << kIdxBits) | (uint32_t)(t_begin + (int)local) : kNoKey;
+    };
+    uint2* out = a.keys + ((size_t)problem * a.splits + split) * (size_t)a.rows_max;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        uint32_t k1 = to_key(m1[n]), k2 = to_key(m2[n]);
+        const uint32_t o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32);
+        top2(k1, k2, o1);
+        top2(k1, k2, o2);
+        const int qi = q0 + wave * kQPerWave + 32 * n + li;
+        if (lh == 0 && qi < nq) out[qi] = make_uint2(k1, k2);
+    }
+}
+
+}  // namespace
+
+int hamming_mfma_q_per_block(int row_words) {
+    switch (row_words) {
+        case 4:
+        case 8: return kWaves * 64;
+        case 16: return kWaves * 32;  // 64-byte rows: one query tile per wave fits the registers
+        default: return 0;
+    }
+}
+
+MfmaPlan make_mfma_plan(const sfm_ctx* ctx, int row_words, int rows_max, int n_problems) {
+    MfmaPlan p{};
+    p.row_words = row_words;
+    p.rows_max = rows_max;
+    const int qpb = hamming_mfma_q_per_block(row_words);
+    p.qtiles = qpb ? (rows_max + qpb - 1) / qpb : 0;
+    const int tiles = (rows_max + kTileRows - 1) / kTileRows;
+    const int tiles_cap = (1 << kLocalBits) / kTileRows;   // rows per range the keys can index
+    int min_splits = (tiles + tiles_cap - 1) / tiles_cap;
+    // one workgroup per CU at a time: aim at four rounds of them
+    const long want = 4L * ctx->num_cus;
+    const long blocks = (long)p.qtiles * n_problems;
+    int splits = blocks > 0 ? (int)((want + blocks - 1) / blocks) : 1;
+    if (splits > tiles / 2) splits = tiles / 2;  // at least two tiles per range
+    if (splits < min_splits) splits = min_splits;
+    if (splits < 1) splits = 1;
+    const int per = (tiles + splits - 1) / splits;
+    p.splits = per > 0 ? (tiles + per - 1) / per : 1;
+    if (p.splits < 1) p.splits = 1;
+    return p;
+}
+
+size_t hamming_mfma_frame_bytes(int row_words, int rows) { return (size_t)rows * row_words * 32; }
+
+int launch_hamming_expand(sfm_ctx* ctx, const void* packed, size_t frame_stride, int row_words,
+                          int rows, int n_frames, void* d_rows) {
+    if (rows <= 0 || n_frames <= 0) return SFM_OK;
+    const size_t units = (size_t)rows * row_words * 2 * n_frames;
+    const size_t grid = (units + 255) / 256;
+    if (grid > 0x7fffffffUL) return set_error(ctx, SFM_E_INVALID, "expand launch too large");
+    KernelTimer timer(ctx, KID_HAMMING_EXPAND);
+    hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream,
+                       static_cast<const uint32_t*>(packed), frame_stride / 4, row_words, rows,
+                       n_frames, static_cast<uint4*>(d_rows));
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+int launch_hamming_mfma(sfm_ctx* ctx, const MfmaPlan& plan, const void* d_rows, int rows_uniform,
+                        const int32_t* d_counts, const int32_t* d_pairs, int n_pairs,
+                        uint32_t* d_keys) {
+    if (n_pairs <= 0) return SFM_OK;
+    if (plan.qtiles <= 0) return set_error(ctx, SFM_E_UNSUPPORTED, "no matrix kernel for %d-word rows", plan.row_words);
+    MfmaArgs a{};
+    a.rows = static_cast<const uint8_t*>(d_rows);
+    a.frame_bytes = hamming_mfma_frame_bytes(plan.row_words, rows_uniform);
+    a.counts = d_counts;
+    a.rows_uniform = rows_uniform;
+    a.pairs = d_pairs;
+    a.n_problems = 2 * n_pairs;
+    a.qtiles = plan.qtiles;
+    a.splits = plan.splits;
+    a.rows_max = plan.rows_max;
+    a.keys = reinterpret_cast<uint2*>(d_keys);
+    a.grouped = a.n_problems >= 64 ? 1 : 0;
+    const long padded = a.grouped ? (long)((a.n_problems + 7) / 8) * 8 : a.n_problems;
+    const long grid = padded * plan.qtiles * plan.splits;
+    if (grid > 0x7fffffffL) return set_error(ctx, SFM_E_INVALID, "matrix launch too large");
+    KernelTimer timer(ctx, KID_HAMMING_MFMA);
+    switch (plan.row_words) {
+        case 4:
+            hipLaunchKernelGGL((hamming_mfma_kernel<4, 2>), dim3((unsigned)grid), dim3(kThreads), 0,
+                               ctx->stream, a);
+            break;
+        case 8:
+            hipLaunchKernelGGL((hamming_mfma_kernel<8, 2>), dim3((unsigned)grid), dim3(kThreads), 0,
+                               ctx->stream, a);
+            break;
+        case 16:
+            hipLaunchKernelGGL((hamming_mfma_kernel<16, 1>), dim3((unsigned)grid), dim3(kThreads), 0,
+                               ctx->stream, a);
+            break;
+        default:
+            return set_error(ctx, SFM_E_UNSUPPORTED, "no matrix kernel for %d-word rows", plan.row_words);
+    }
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+}  // namespace sfm

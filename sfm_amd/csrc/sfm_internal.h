@@ -42,6 +42,8 @@ enum KernelId {
     KID_EM_SOLVE,
     KID_EM_SCORE,
     KID_POSE,
+    KID_HAMMING_MFMA,
+    KID_HAMMING_EXPAND,
     KID_COUNT
 };
 struct TimedLaunch {
@@ -182,6 +184,28 @@ int launch_ratio_cross_pairs(sfm_ctx* ctx, const PairPlan& plan, const uint32_t*
                              const int32_t* d_pairs, int n_pairs, float ratio, int32_t* d_best,
                              float* d_best_dist, sfm_dmatch* d_matches, int cap,
                              int32_t* d_match_counts);
+
+// Both directions of every pair on the integer matrix cores (hamming_mfma.hip).
+struct MfmaPlan {
+    int row_words;
+    int rows_max;
+    int qtiles;   // workgroups along the query rows; 0: no kernel for this row width
+    int splits;   // workgroups along the train rows
+};
+// Query rows one workgroup owns, or 0 when no matrix kernel exists for that row width.
+int hamming_mfma_q_per_block(int row_words);
+MfmaPlan make_mfma_plan(const sfm_ctx* ctx, int row_words, int rows_max, int n_problems);
+// Bytes of one frame of `rows` rows in the signed-byte form the matrix kernel reads.
+size_t hamming_mfma_frame_bytes(int row_words, int rows);
+// Packed frames (row_words words per row, frame_stride bytes apart) -> signed-byte frames,
+// hamming_mfma_frame_bytes apart.
+int launch_hamming_expand(sfm_ctx* ctx, const void* packed, size_t frame_stride, int row_words,
+                          int rows, int n_frames, void* d_rows);
+// Writes keys[problem][split][rows_max][2], the layout launch_ratio_cross reads with
+// plan.splits parts per direction.
+int launch_hamming_mfma(sfm_ctx* ctx, const MfmaPlan& plan, const void* d_rows, int rows_uniform,
+                        const int32_t* d_counts, const int32_t* d_pairs, int n_pairs,
+                        uint32_t* d_keys);
 
 // Merges the splits of a single problem and writes idx/dist [nq][2].
 int launch_knn_finalize(sfm_ctx* ctx, const KnnPlan& plan, const uint32_t* d_keys, int nq,

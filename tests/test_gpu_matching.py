@@ -212,13 +212,16 @@ def test_robust_matches_strided_rows(ctx, oracle):
     (13, 1300, [1300, 511, 257, 90, 1299, 3]),      # padded to 16 bytes first
     (64, 1300, [1300, 300, 700, 2, 1025, 65]),      # 64-byte descriptors: two rows of prev per lane
 ])
-def test_match_pairs_ragged(ctx, oracle, d, rows, counts):
-    """Every pair of six frames with very different row counts, against the oracle (30 pairs
-    of this size go through the one-pass pair kernel)."""
+@pytest.mark.parametrize("path", ["", "0", "1", "2"])
+def test_match_pairs_ragged(ctx, oracle, monkeypatch, d, rows, counts, path):
+    """Every pair of six frames with very different row counts, against the oracle, through
+    each of the three Hamming kernels (SFM_PAIR_KERNEL: 0 single-direction, 1 one-pass pair
+    kernel, 2 matrix-core kernel) and through the one the library picks by size."""
     import torch
 
     from sfm_amd import capi
 
+    monkeypatch.setenv("SFM_PAIR_KERNEL", path)
     rng = np.random.default_rng(1000 + d)
     n_frames = len(counts)
     base = rng.integers(0, 256, size=(rows, d), dtype=np.uint8)
