@@ -13,13 +13,13 @@
 // ranking key  8192 * h + local train index  (a workgroup's range holds at most 8192 rows): no
 // instruction builds keys.  Train tiles are the A operand (rows), the queries the B operand
 // (columns): each lane's 16 accumulator registers are 16 train rows of ONE query, so the
-// running best-two of that query stay in two of the lane's registers and take one v_med3_u32
-// and one v_min_u32 per distance.  The minimum of (distance, index) keys does not depend on
-// the visiting order, so the neighbours, ties included, are those of the scalar kernels
+// running best-two of that query stay in the lane's registers and take three instructions per
+// two distances (top2_pair).  The minimum of (distance, index) keys does not depend on the
+// visiting order, so the neighbours, ties included, are those of the scalar kernels
 // (hamming_knn2.hip, hamming_pair.hip).
 //
 // The signed-byte rows are written once per frame by hamming_expand_kernel; a workgroup keeps
-// its 512 queries (8 waves x 64) in registers for its whole life and streams 64-row train
+// its 512 queries (8 waves x 64) in registers for its whole life and streams 128-row train
 // tiles global -> LDS (XOR-swizzled so that the 16-byte fragment reads are conflict-free),
 // double-buffered.  Two accumulator sets alternate, one per 32-row half of a tile: while the
 // matrix pipe works on one half the vector ALU folds the previous one into the best-two lists,
@@ -35,7 +35,7 @@ typedef int intx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
-constexpr int kTileRows = 64;        // train rows per LDS tile: two 32-row MFMA tiles
+constexpr int kTileUnit = 64;        // train ranges are whole multiples of this many rows
 constexpr int kLocalBits = 13;       // a workgroup's train range holds at most 2^13 rows
 constexpr int kIdxBits = 18;         // index bits of the keys the merge kernels read
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
@@ -56,10 +56,18 @@ struct MfmaArgs {
     uint2* keys;             // [problem][split][rows_max]
 };
 
-// Median of three; the compiler turns this form into one v_med3_u32.  (Not inline asm: the
-// instruction scheduler must see a vector ALU instruction to place it between the MFMAs.)
+// Written as asm: from the min / max forms the compiler shares subexpressions between the
+// median and the minimum and ends up with more instructions.
 __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
-    return max(min(a, b), min(max(a, b), c));
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lptr, 16, 0, 0);
 }
 
 __device__ __forceinline__ void top2(uint32_t& m1, uint32_t& m2, uint32_t key) {
@@ -67,9 +75,11 @@ __device__ __forceinline__ void top2(uint32_t& m1, uint32_t& m2, uint32_t key) {
     m1 = min(m1, key);
 }
 
-__device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
-                                     (__attribute__((address_space(3))) void*)lptr, 16, 0, 0);
+// Two keys at once in three instructions (v_med3, v_min, v_min3) instead of four: with
+// m1 <= m2, the second smallest of {m1, m2, x, y} is min(m2, median(m1, x, y)).
+__device__ __forceinline__ void top2_pair(uint32_t& m1, uint32_t& m2, uint32_t x, uint32_t y) {
+    m2 = min(m2, med3_u32(m1, x, y));
+    asm("v_min3_u32 %0, %0, %1, %2" : "+v"(m1) : "v"(x), "v"(y));
 }
 
 // One thread per 16 output bytes: 16 bits of a packed row become 16 signed bytes,
@@ -94,15 +104,17 @@ __global__ __launch_bounds__(256) void hamming_expand_kernel(const uint32_t* __r
     out[i] = make_uint4(d[0], d[1], d[2], d[3]);
 }
 
-// W: 32-bit words per packed row (the contraction length is 32 W), NT: 32-query tiles per wave.
-template <int W, int NT>
+// W: 32-bit words per packed row (the contraction length is 32 W), NT: 32-query tiles per wave,
+// kTileRows: train rows per LDS tile (a multiple of 64).
+template <int W, int NT, int kTileRows>
 __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
     constexpr int kRowBytes = 32 * W;
     constexpr int kCpr = kRowBytes / 16;                 // 16-byte chunks per row
     constexpr int kSwz = kCpr < 16 ? kCpr - 1 : 15;
     constexpr int kTileBytes = kTileRows * kRowBytes;
-    constexpr int kStagePerWave = kCpr / kWaves;         // 1 KiB wave-instructions per wave and tile
-    static_assert(kCpr % kWaves == 0, "a tile must split evenly over the waves");
+    constexpr int kStagePerWave = kTileRows * kCpr / 64 / kWaves;  // 1 KiB wave-instructions per wave and tile
+    static_assert((kTileRows * kCpr / 64) % kWaves == 0, "a tile must split evenly over the waves");
+    static_assert(kTileRows % kTileUnit == 0, "whole 64-row units");
     constexpr int kQPerWave = 32 * NT;
     constexpr int kQPerBlock = kWaves * kQPerWave;
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kTileBytes];
@@ -146,19 +158,23 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
             breg[n][m] = v ^ (int)0x80808080;  // +-64 -> -+64
         }
     }
-    uint32_t m1[NT], m2[NT];
+    // best two per query tile, kept twice (even and odd accumulator registers) so that the
+    // vector ALU always has independent chains to issue from; merged at the end
+    uint32_t m1[NT][2], m2[NT][2];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) m1[n] = m2[n] = kEmpty;
+    for (int n = 0; n < NT; ++n) m1[n][0] = m1[n][1] = m2[n][0] = m2[n][1] = kEmpty;
 
     // this workgroup's train range: whole tiles, at most 2^kLocalBits rows
-    const int tiles_total = (nt + kTileRows - 1) / kTileRows;
-    const int tiles_per_split = (tiles_total + a.splits - 1) / a.splits;
-    const int t_begin = split * tiles_per_split * kTileRows;
-    const int t_end = min(nt, t_begin + tiles_per_split * kTileRows);
+    const int units_total = (nt + kTileUnit - 1) / kTileUnit;
+    const int units_per_split = (units_total + a.splits - 1) / a.splits;
+    const int t_begin = split * units_per_split * kTileUnit;
+    const int t_end = min(nt, t_begin + units_per_split * kTileUnit);
     const int ntiles = t_end > t_begin ? (t_end - t_begin + kTileRows - 1) / kTileRows : 0;
 
     // global -> LDS copy of one tile: LDS position p (16-byte chunks, linear) holds chunk
     // (p % kCpr) ^ (row & kSwz) of row p / kCpr; each wave instruction fills 64 positions.
+    // (Staging through registers instead lets the compiler wait for single fragment reads
+    // rather than for all outstanding ones, but measured 2 % slower.)
     auto stage = [&](int k, int buf) {
         const int tbase = t_begin + k * kTileRows;
         uint8_t* dst = lds + buf * kTileBytes;
@@ -177,58 +193,79 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
     if (ntiles > 0) stage(0, 0);
 
     // accumulator start: register r of a 32-row half tile is its train row 8(r>>2) + 4lh + (r&3);
-    // it starts at 4096 * bits + the row's index in the workgroup's range
-    intx16 init;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) init[r] = 4096 * kRowBytes + 8 * (r >> 2) + 4 * lh + (r & 3);
+    // it starts at 4096 * bits + the row's index in the workgroup's range.  The start values of
+    // a half tile are formed afresh (a per-lane constant + one scalar per register): a vector
+    // updated in place would be live across the MFMAs that start from it and cost a register
+    // copy per half tile.
+    const int lane_base = 4096 * kRowBytes + 4 * lh;
     __syncthreads();
 
     // Two accumulator sets, one per half of a tile.  While the matrix pipe accumulates one half
     // tile into one set, the vector ALU folds the other set (the previous half tile) into the
     // best-two lists, a slice of it after every k step, so the fold hides behind the MFMAs.
-    constexpr int kGroups = NT * 4;  // groups of 4 accumulator registers per set
+    constexpr int kGroups = 4;  // slices of a set: 4 accumulator registers of every query tile
     intx16 acc0[NT], acc1[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[n][r] = acc1[n][r] = kMasked;
 
-    auto fold_group = [&](const intx16 (&acc)[NT], int gi) {
-        const int n = gi / 4, gq = gi % 4;
+    auto fold_group = [&](const intx16 (&acc)[NT], int gq) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) top2(m1[n], m2[n], (uint32_t)acc[n][4 * gq + r]);
+        for (int r = 0; r < 4; r += 2)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                top2_pair(m1[n][r >> 1], m2[n][r >> 1], (uint32_t)acc[n][4 * gq + r],
+                          (uint32_t)acc[n][4 * gq + r + 1]);
     };
 
     const int left = t_end - t_begin;
-    auto mask_init = [&]() {  // the last tile may hold rows past the range
+    // One tile: kSteps k steps (W per 32-row half tile), the A fragments read two k steps
+    // ahead through a ring of three.  first: index of the tile's first row in the range;
+    // masked: the tile may hold rows past the range (the last tile only).
+    constexpr int kHalves = kTileRows / 32;
+    constexpr int kSteps = kHalves * W;
+    const int swz = li & kSwz;                       // 32-row pieces keep row & kSwz == li & kSwz
+    const int lane_off = li * kRowBytes;
+    auto tile_body = [&](const uint8_t* tile, int first, bool masked) {
+        const uint8_t* rowp = tile + lane_off;
+        auto frag = [&](int s) {
+            const int mt = s / W, m = s % W;
+            return *reinterpret_cast<const intx4*>(rowp + mt * (32 * kRowBytes) +
+                                                   (((2 * m + lh) ^ swz) * 16));
+        };
+        intx4 ring[3];
+        ring[0] = frag(0);
+        ring[1] = frag(1);
+#pragma clang loop unroll(full)
+        for (int s = 0; s < kSteps; ++s) {
+            const int mt = s / W, m = s % W;
+            if (s + 2 < kSteps) ring[(s + 2) % 3] = frag(s + 2);
+            intx16 (&accC)[NT] = (mt & 1) ? acc1 : acc0;
+            const intx16 (&accF)[NT] = (mt & 1) ? acc0 : acc1;
+            intx16 start;
+            if (m == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if ((init[r] & ((1 << kLocalBits) - 1)) >= left) init[r] = kMasked;
-    };
-    auto half_step = [&](intx16 (&accC)[NT], const intx16 (&accF)[NT], const uint8_t* tile, int mt) {
-        const int row = 32 * mt + li;
-        const uint8_t* rowp = tile + row * kRowBytes;
-        const int swz = row & kSwz;
-        intx4 av = *reinterpret_cast<const intx4*>(rowp + (lh ^ swz) * 16), av_next;
+                for (int r = 0; r < 16; ++r)
+                    start[r] = lane_base + (first + 32 * mt + 8 * (r >> 2) + (r & 3));
+                if (masked) {
 #pragma unroll
-        for (int m = 0; m < W; ++m) {
-            if (m + 1 < W)
-                av_next = *reinterpret_cast<const intx4*>(rowp + ((2 * (m + 1) + lh) ^ swz) * 16);
+                    for (int r = 0; r < 16; ++r)
+                        if ((start[r] & ((1 << kLocalBits) - 1)) >= left) start[r] = kMasked;
+                }
+            }
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                accC[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, breg[n][m],
-                                                                m == 0 ? init : accC[n], 0, 0, 0);
+                accC[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ring[s % 3], breg[n][m],
+                                                                m == 0 ? start : accC[n], 0, 0, 0);
             // The fold of the other set starts one k step late (that set's last MFMAs were
-            // issued just before this half tile; the first k step advances the start values
-            // to the next half tile instead) and is spread over the remaining k steps.
-            if (m == 0) {
-                init += 32;
-            } else {
+            // issued just before this half tile) and is spread over the remaining k steps.
+            if (m > 0) {
 #pragma unroll
                 for (int gi = ((m - 1) * kGroups) / (W - 1); gi < (m * kGroups) / (W - 1); ++gi)
                     fold_group(accF, gi);
             }
-            av = av_next;
+
             // keep every k step's MFMAs and its share of the fold together: the compiler
             // otherwise gathers the whole fold in front of the MFMAs
             __builtin_amdgcn_sched_barrier(0);
@@ -238,18 +275,10 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
     for (int k = 0; k + 1 < ntiles; ++k) {
         const int buf = k & 1;
         stage(k + 1, buf ^ 1);
-        const uint8_t* tile = lds + buf * kTileBytes;
-        half_step(acc0, acc1, tile, 0);
-        half_step(acc1, acc0, tile, 1);
+        tile_body(lds + buf * kTileBytes, k * kTileRows, false);
         __syncthreads();
     }
-    if (ntiles > 0) {
-        const uint8_t* tile = lds + ((ntiles - 1) & 1) * kTileBytes;
-        mask_init();
-        half_step(acc0, acc1, tile, 0);
-        mask_init();
-        half_step(acc1, acc0, tile, 1);
-    }
+    if (ntiles > 0) tile_body(lds + ((ntiles - 1) & 1) * kTileBytes, (ntiles - 1) * kTileRows, true);
 #pragma unroll
     for (int gi = 0; gi < kGroups; ++gi) fold_group(acc1, gi);
 
@@ -261,7 +290,9 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
     uint2* out = a.keys + ((size_t)problem * a.splits + split) * (size_t)a.rows_max;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        uint32_t k1 = to_key(m1[n]), k2 = to_key(m2[n]);
+        uint32_t k1 = to_key(m1[n][0]), k2 = to_key(m2[n][0]);
+        top2(k1, k2, to_key(m1[n][1]));
+        top2(k1, k2, to_key(m2[n][1]));
         const uint32_t o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32);
         top2(k1, k2, o1);
         top2(k1, k2, o2);
@@ -287,8 +318,8 @@ MfmaPlan make_mfma_plan(const sfm_ctx* ctx, int row_words, int rows_max, int n_p
     p.rows_max = rows_max;
     const int qpb = hamming_mfma_q_per_block(row_words);
     p.qtiles = qpb ? (rows_max + qpb - 1) / qpb : 0;
-    const int tiles = (rows_max + kTileRows - 1) / kTileRows;
-    const int tiles_cap = (1 << kLocalBits) / kTileRows;   // rows per range the keys can index
+    const int tiles = (rows_max + kTileUnit - 1) / kTileUnit;
+    const int tiles_cap = (1 << kLocalBits) / kTileUnit;   // rows per range the keys can index
     int min_splits = (tiles + tiles_cap - 1) / tiles_cap;
     // one workgroup per CU at a time: aim at four rounds of them
     const long want = 4L * ctx->num_cus;
@@ -342,15 +373,15 @@ int launch_hamming_mfma(sfm_ctx* ctx, const MfmaPlan& plan, const void* d_rows, 
     KernelTimer timer(ctx, KID_HAMMING_MFMA);
     switch (plan.row_words) {
         case 4:
-            hipLaunchKernelGGL((hamming_mfma_kernel<4, 2>), dim3((unsigned)grid), dim3(kThreads), 0,
+            hipLaunchKernelGGL((hamming_mfma_kernel<4, 2, 128>), dim3((unsigned)grid), dim3(kThreads), 0,
                                ctx->stream, a);
             break;
         case 8:
-            hipLaunchKernelGGL((hamming_mfma_kernel<8, 2>), dim3((unsigned)grid), dim3(kThreads), 0,
+            hipLaunchKernelGGL((hamming_mfma_kernel<8, 2, 128>), dim3((unsigned)grid), dim3(kThreads), 0,
                                ctx->stream, a);
             break;
         case 16:
-            hipLaunchKernelGGL((hamming_mfma_kernel<16, 1>), dim3((unsigned)grid), dim3(kThreads), 0,
+            hipLaunchKernelGGL((hamming_mfma_kernel<16, 1, 64>), dim3((unsigned)grid), dim3(kThreads), 0,
                                ctx->stream, a);
             break;
         default:
