@@ -54,10 +54,11 @@ enum HammingPath {
     kPathMfma = 2    // hamming_mfma_kernel: signed-byte contraction on the matrix cores
 };
 // SFM_PAIR_KERNEL=0/1/2 forces a path wherever the row width allows it (a debugging and
-// measurement aid); unset, the size decides.  The matrix kernel's workgroup owns 512 queries
-// and at least two 64-row train tiles, the pair kernel's wave 256 rows of prev against 256 of
-// curr: both need enough such units to occupy the chip, and a single small pair is faster
-// through the finely split single-direction kernel.
+// measurement aid).  Unset: the matrix kernel for 16-, 32- and 64-byte descriptors with at
+// least 128 rows per frame -- it was the fastest of the three from one 500 x 500 pair to 32
+// pairs of 8192 x 8192 (tools/hamming_paths.py); otherwise the pair kernel when there are
+// enough of its coarse units (one wave: 256 rows of prev against 256 of curr) to occupy the
+// chip, else the finely split single-direction kernel.
 HammingPath hamming_path(const sfm_ctx* ctx, int row_words, int rows_max, int n_pairs) {
     const char* e = getenv("SFM_PAIR_KERNEL");  // read per call: tests switch it in-process
     const int mode = e && *e ? atoi(e) : -1;
@@ -67,7 +68,7 @@ HammingPath hamming_path(const sfm_ctx* ctx, int row_words, int rows_max, int n_
     if (mode == 1) return pair_ok ? kPathPair : kPathKnn2;
     if (mode == 2) return mfma_ok ? kPathMfma : kPathKnn2;
     const long tiles = (rows_max + 255) / 256;
-    if (mfma_ok && (long)n_pairs * tiles * tiles >= ctx->num_cus / 4) return kPathMfma;
+    if (mfma_ok) return kPathMfma;
     if (pair_ok && (long)n_pairs * tiles * tiles >= 3L * ctx->num_cus) return kPathPair;
     return kPathKnn2;
 }
@@ -85,8 +86,8 @@ int hamming_pairs_packed(sfm_ctx* ctx, const KnnPlan& plan, HammingPath path, co
         uint32_t* keys = c.take<uint32_t>(nprob * mp.splits * mp.rows_max * 2);
         int32_t* best = c.take<int32_t>(nprob * plan.rows_max);
         float* best_dist = c.take<float>(nprob * plan.rows_max);
-        SFM_RETURN_IF(launch_hamming_mfma(ctx, mp, expanded, rows_uniform, d_counts, d_pairs, n_pairs,
-                                          keys));
+        SFM_RETURN_IF(launch_hamming_mfma(ctx, mp, expanded, expanded, rows_uniform, rows_uniform,
+                                          d_counts, d_pairs, n_pairs, keys));
         KnnPlan merged = plan;
         merged.splits = mp.splits;
         return launch_ratio_cross(ctx, merged, keys, d_counts, rows_uniform, rows_uniform, d_pairs,
@@ -159,9 +160,20 @@ int sfm_knn2_dev(sfm_ctx* ctx, int norm, const void* d_q, int nq, size_t q_strid
     const size_t row_bytes = (size_t)plan.row_words * 4;
     const bool q_ok = is_packed(d_q, q_stride, d, plan.row_words);
     const bool t_ok = nt == 0 || is_packed(d_t, t_stride, d, plan.row_words);
+    // the matrix kernel (see hamming_path) when both sets are large enough for its tiles
+    const bool mfma = nt >= 128 && hamming_path(ctx, plan.row_words, nq, 1) == kPathMfma;
+    const MfmaPlan mp = mfma ? make_mfma_plan(ctx, plan.row_words, std::max(nq, nt), 1) : MfmaPlan{};
+    if (mfma) {
+        plan.splits = mp.splits;  // the key layout the matrix kernel writes
+        plan.rows_max = mp.rows_max;
+    }
     Carver sz(nullptr);
     if (!q_ok) sz.take<uint8_t>((size_t)nq * row_bytes);
     if (!t_ok) sz.take<uint8_t>((size_t)nt * row_bytes);
+    if (mfma) {
+        sz.take<uint8_t>(hamming_mfma_frame_bytes(plan.row_words, nq));
+        sz.take<uint8_t>(hamming_mfma_frame_bytes(plan.row_words, nt));
+    }
     sz.take<uint32_t>((size_t)plan.splits * plan.rows_max * 2);
     void* ws;
     SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
@@ -177,6 +189,15 @@ int sfm_knn2_dev(sfm_ctx* ctx, int norm, const void* d_q, int nq, size_t q_strid
         void* p = c.take<uint8_t>((size_t)nt * row_bytes);
         SFM_RETURN_IF(pack_rows(ctx, d_t, nt, t_stride, d, p, plan.row_words));
         tp = p;
+    }
+    if (mfma) {
+        void* qe = c.take<uint8_t>(hamming_mfma_frame_bytes(plan.row_words, nq));
+        void* te = c.take<uint8_t>(hamming_mfma_frame_bytes(plan.row_words, nt));
+        uint32_t* keys = c.take<uint32_t>((size_t)plan.splits * plan.rows_max * 2);
+        SFM_RETURN_IF(launch_hamming_expand(ctx, qp, (size_t)nq * row_bytes, plan.row_words, nq, 1, qe));
+        SFM_RETURN_IF(launch_hamming_expand(ctx, tp, (size_t)nt * row_bytes, plan.row_words, nt, 1, te));
+        SFM_RETURN_IF(launch_hamming_mfma(ctx, mp, qe, te, nq, nt, nullptr, nullptr, 0, keys));
+        return launch_knn_finalize(ctx, plan, keys, nq, nt, d_idx, d_dist);
     }
     uint32_t* keys = c.take<uint32_t>((size_t)plan.splits * plan.rows_max * 2);
     KnnBatch b{};

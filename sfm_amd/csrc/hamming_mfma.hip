@@ -44,11 +44,13 @@ constexpr int kMasked = 0x40000000;        // accumulator start of a row past th
 constexpr uint32_t kRealLimit = 0x20000000u;
 
 struct MfmaArgs {
-    const uint8_t* rows;     // signed-byte frames: frame f at rows + f * frame_bytes
+    const uint8_t* q_rows;   // signed-byte frames: frame f at q_rows + f * frame_bytes
+    const uint8_t* t_rows;   // (the same array for frame pairs)
     size_t frame_bytes;
     const int32_t* counts;   // per-frame row counts or nullptr
-    int rows_uniform;
-    const int32_t* pairs;    // [n_pairs][2]; problem 2p is (a -> b), 2p + 1 is (b -> a)
+    int nq_uniform, nt_uniform;
+    const int32_t* pairs;    // [n_pairs][2]; problem 2p is (a -> b), 2p + 1 is (b -> a);
+                             // nullptr: one problem, q_rows against t_rows
     int n_problems;
     int qtiles, splits;
     int rows_max;
@@ -133,16 +135,20 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
         inner = blockIdx.x % per_problem;
     }
     if (problem >= a.n_problems) return;
-    const int pair = problem >> 1, dir = problem & 1;
-    const int fa = a.pairs[2 * pair], fb = a.pairs[2 * pair + 1];
-    const int qf = dir ? fb : fa, tf = dir ? fa : fb;
-    const int nq = a.counts ? a.counts[qf] : a.rows_uniform;
-    const int nt = a.counts ? a.counts[tf] : a.rows_uniform;
+    int qf = 0, tf = 0;
+    if (a.pairs) {
+        const int pair = problem >> 1, dir = problem & 1;
+        const int fa = a.pairs[2 * pair], fb = a.pairs[2 * pair + 1];
+        qf = dir ? fb : fa;
+        tf = dir ? fa : fb;
+    }
+    const int nq = a.counts ? a.counts[qf] : a.nq_uniform;
+    const int nt = a.counts ? a.counts[tf] : a.nt_uniform;
     const int qtile = inner / a.splits, split = inner % a.splits;
     const int q0 = qtile * kQPerBlock;
     if (q0 >= nq) return;  // the merge reads only rows below nq
-    const uint8_t* qrows = a.rows + (size_t)qf * a.frame_bytes;
-    const uint8_t* trows = a.rows + (size_t)tf * a.frame_bytes;
+    const uint8_t* qrows = a.q_rows + (size_t)qf * a.frame_bytes;
+    const uint8_t* trows = a.t_rows + (size_t)tf * a.frame_bytes;
 
     // B operand: the negated signed bytes of this lane's queries, resident for the whole kernel.
     // breg[n][m] holds bits 32m + 16lh .. + 15 of query q0 + wave * kQPerWave + 32n + li.
@@ -350,18 +356,21 @@ int launch_hamming_expand(sfm_ctx* ctx, const void* packed, size_t frame_stride,
     return SFM_OK;
 }
 
-int launch_hamming_mfma(sfm_ctx* ctx, const MfmaPlan& plan, const void* d_rows, int rows_uniform,
+int launch_hamming_mfma(sfm_ctx* ctx, const MfmaPlan& plan, const void* d_q_rows,
+                        const void* d_t_rows, int nq_uniform, int nt_uniform,
                         const int32_t* d_counts, const int32_t* d_pairs, int n_pairs,
                         uint32_t* d_keys) {
-    if (n_pairs <= 0) return SFM_OK;
+    if (d_pairs && n_pairs <= 0) return SFM_OK;
     if (plan.qtiles <= 0) return set_error(ctx, SFM_E_UNSUPPORTED, "no matrix kernel for %d-word rows", plan.row_words);
     MfmaArgs a{};
-    a.rows = static_cast<const uint8_t*>(d_rows);
-    a.frame_bytes = hamming_mfma_frame_bytes(plan.row_words, rows_uniform);
+    a.q_rows = static_cast<const uint8_t*>(d_q_rows);
+    a.t_rows = static_cast<const uint8_t*>(d_t_rows);
+    a.frame_bytes = hamming_mfma_frame_bytes(plan.row_words, nq_uniform);
     a.counts = d_counts;
-    a.rows_uniform = rows_uniform;
+    a.nq_uniform = nq_uniform;
+    a.nt_uniform = nt_uniform;
     a.pairs = d_pairs;
-    a.n_problems = 2 * n_pairs;
+    a.n_problems = d_pairs ? 2 * n_pairs : 1;
     a.qtiles = plan.qtiles;
     a.splits = plan.splits;
     a.rows_max = plan.rows_max;

@@ -201,9 +201,12 @@ size_t hamming_mfma_frame_bytes(int row_words, int rows);
 // hamming_mfma_frame_bytes apart.
 int launch_hamming_expand(sfm_ctx* ctx, const void* packed, size_t frame_stride, int row_words,
                           int rows, int n_frames, void* d_rows);
-// Writes keys[problem][split][rows_max][2], the layout launch_ratio_cross reads with
-// plan.splits parts per direction.
-int launch_hamming_mfma(sfm_ctx* ctx, const MfmaPlan& plan, const void* d_rows, int rows_uniform,
+// Writes keys[problem][split][rows_max][2], the layout launch_ratio_cross and
+// launch_knn_finalize read with plan.splits parts per direction.  With d_pairs: both
+// directions of every pair of frames of one array (d_q_rows == d_t_rows, nq_uniform ==
+// nt_uniform rows per frame).  Without: the single problem d_q_rows against d_t_rows.
+int launch_hamming_mfma(sfm_ctx* ctx, const MfmaPlan& plan, const void* d_q_rows,
+                        const void* d_t_rows, int nq_uniform, int nt_uniform,
                         const int32_t* d_counts, const int32_t* d_pairs, int n_pairs,
                         uint32_t* d_keys);
 

@@ -65,12 +65,19 @@ def test_hamming_empty_inputs(ctx):
     assert len(ctx.ratio_matches(capi.NORM_HAMMING, q, q[:1], 0.8)) == 0
 
 
+@pytest.mark.parametrize("path", ["", "0"])
 @pytest.mark.parametrize("nq,nt,d", [(2000, 2000, 32), (1500, 2300, 32), (777, 1031, 61),
                                      (1024, 512, 64), (300, 5000, 16), (64, 257, 128),
-                                     (100, 90, 256), (513, 700, 7)])
-def test_hamming_knn2_vs_oracle(ctx, oracle, nq, nt, d):
+                                     (100, 90, 256), (513, 700, 7), (700, 9000, 32),
+                                     (129, 128, 64), (600, 8193, 16)])
+def test_hamming_knn2_vs_oracle(ctx, oracle, monkeypatch, nq, nt, d, path):
+    """Single-direction 2-NN, ties included, through the kernel the library picks (the
+    matrix-core kernel for 16/32/64-byte rows and at least 128 rows a side; above 8192 train
+    rows it works in more than one train range) and through the scalar kernel
+    (SFM_PAIR_KERNEL=0)."""
     from sfm_amd import capi
 
+    monkeypatch.setenv("SFM_PAIR_KERNEL", path)
     rng = np.random.default_rng(nq * 31 + nt)
     q = rng.integers(0, 256, size=(nq, d), dtype=np.uint8)
     t = rng.integers(0, 256, size=(nt, d), dtype=np.uint8)
