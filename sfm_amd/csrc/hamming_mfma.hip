@@ -1,29 +1,34 @@
 // Hamming 2-nearest-neighbour search of many (query frame, train frame) problems on the
-// integer matrix cores of gfx950.
+// matrix cores of gfx950.
 //
 // Replaces the two cv::BFMatcher(NORM_HAMMING)::knnMatch(.., 2) calls of
-// DescriptorMatcher::findRobustMatches (Source Files/feature_processing.cpp:148-149) when a
-// launch holds enough of them to fill the chip.
+// DescriptorMatcher::findRobustMatches (Source Files/feature_processing.cpp:148-149) and the
+// one of DescriptorMatcher::ratioMaches (:121).
 //
-// popcount(q ^ t) over B bits is a contraction: with every bit written as a signed byte,
-// s(0) = +64 and s(1) = -64, a train row as s(t) and a query row as -s(q),
-//     sum_k s(t_k) * (-s(q_k)) = 4096 * (#differing - #equal) = 8192 * h - 4096 * B.
-// v_mfma_i32_32x32x32_i8 forms it exactly in int32.  The accumulator of train row r starts at
-// 4096 * B + (r - first row of the workgroup's train range), so when the k loop ends it IS the
-// ranking key  8192 * h + local train index  (a workgroup's range holds at most 8192 rows): no
-// instruction builds keys.  Train tiles are the A operand (rows), the queries the B operand
-// (columns): each lane's 16 accumulator registers are 16 train rows of ONE query, so the
-// running best-two of that query stay in the lane's registers and take three instructions per
-// two distances (top2_pair).  The minimum of (distance, index) keys does not depend on the
+// popcount(q ^ t) over B bits is a contraction: with every bit written as a signed unit,
+// s(0) = +1 and s(1) = -1, a train row as s(t) and a query row as -s(q),
+//     sum_k s(t_k) * (-s(q_k)) = #differing - #equal = 2 h - B.
+// The units are 4-bit floats (E2M1: +1 = 0x2, -1 = 0xA), the densest operand the matrix pipe
+// takes: v_mfma_scale_f32_32x32x64_f8f6f4 contracts 64 bits per instruction and multiplies
+// each operand by a power-of-two block scale, here 2^6 for both, so one differing bit adds
+// 8192 and the sum is exact in the float accumulator (|sum| <= 4096 B < 2^24).  The
+// accumulator of train row r starts at 4096 B + (r - first row of the workgroup's train
+// range), so when the k loop ends it IS the ranking key  8192 h + local train index  (a
+// workgroup's range holds at most 8192 rows): no instruction builds keys, and positive floats
+// order like their bit patterns, so the lists are kept with integer min / median
+// instructions.  Train tiles are the A operand (rows), the queries the B operand (columns):
+// each lane's 16 accumulator registers are 16 train rows of ONE query, so the running
+// best-two of that query stay in the lane's registers and take three instructions per two
+// distances (top2_pair).  The minimum of (distance, index) keys does not depend on the
 // visiting order, so the neighbours, ties included, are those of the scalar kernels
 // (hamming_knn2.hip, hamming_pair.hip).
 //
-// The signed-byte rows are written once per frame by hamming_expand_kernel; a workgroup keeps
-// its 512 queries (8 waves x 64) in registers for its whole life and streams 128-row train
-// tiles global -> LDS (XOR-swizzled so that the 16-byte fragment reads are conflict-free),
-// double-buffered.  Two accumulator sets alternate, one per 32-row half of a tile: while the
-// matrix pipe works on one half the vector ALU folds the previous one into the best-two lists,
-// a slice after every k step.
+// The 4-bit rows are written once per frame by hamming_expand_kernel (half a byte per
+// descriptor bit); a workgroup keeps its 512 queries (8 waves x 64) in registers for its
+// whole life and streams 128-row train tiles global -> LDS (XOR-swizzled so that the 16-byte
+// fragment reads are conflict-free), double-buffered.  Two accumulator sets alternate, one
+// per 32-row half of a tile: while the matrix pipe works on one half the vector ALU folds the
+// previous one into the best-two lists, a slice after every k step.
 #include "sfm_internal.h"
 
 namespace sfm {
@@ -31,7 +36,8 @@ namespace sfm {
 namespace {
 
 typedef int intx4 __attribute__((ext_vector_type(4)));
-typedef int intx16 __attribute__((ext_vector_type(16)));
+typedef int intx8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
@@ -39,12 +45,14 @@ constexpr int kTileUnit = 64;        // train ranges are whole multiples of this
 constexpr int kLocalBits = 13;       // a workgroup's train range holds at most 2^13 rows
 constexpr int kIdxBits = 18;         // index bits of the keys the merge kernels read
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
-constexpr uint32_t kEmpty = 0x7FFFFFFFu;   // tracker start, above every real accumulator
-constexpr int kMasked = 0x40000000;        // accumulator start of a row past the range
-constexpr uint32_t kRealLimit = 0x20000000u;
+constexpr uint32_t kEmpty = 0x7F7FFFFFu;   // tracker start (FLT_MAX), above every accumulator
+constexpr float kMasked = 1e30f;           // accumulator start of a row past the range
+constexpr float kRealLimit = 1e20f;
+constexpr int kScale = 127 + 6;            // E8M0 block scale 2^6 of both operands
+constexpr int kAhead = 3;                  // fragment reads run this many k steps ahead
 
 struct MfmaArgs {
-    const uint8_t* q_rows;   // signed-byte frames: frame f at q_rows + f * frame_bytes
+    const uint8_t* q_rows;   // 4-bit frames: frame f at q_rows + f * frame_bytes
     const uint8_t* t_rows;   // (the same array for frame pairs)
     size_t frame_bytes;
     const int32_t* counts;   // per-frame row counts or nullptr
@@ -66,7 +74,6 @@ __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
-
 __device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
                                      (__attribute__((address_space(3))) void*)lptr, 16, 0, 0);
@@ -84,34 +91,37 @@ __device__ __forceinline__ void top2_pair(uint32_t& m1, uint32_t& m2, uint32_t x
     asm("v_min3_u32 %0, %0, %1, %2" : "+v"(m1) : "v"(x), "v"(y));
 }
 
-// One thread per 16 output bytes: 16 bits of a packed row become 16 signed bytes,
-// bit 0 -> +64 (0x40), bit 1 -> -64 (0xC0); byte b of a row is bit b of the descriptor.
+// One thread per descriptor word: 32 bits become 32 four-bit floats (16 bytes), bit 0 -> +1
+// (0x2), bit 1 -> -1 (0xA); nibble b of a row is bit b of the descriptor.
 __global__ __launch_bounds__(256) void hamming_expand_kernel(const uint32_t* __restrict__ packed,
                                                              size_t frame_words, int row_words,
                                                              int rows, int n_frames,
                                                              uint4* __restrict__ out) {
-    const size_t per_frame = (size_t)rows * row_words * 2;
+    const size_t per_frame = (size_t)rows * row_words;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= per_frame * n_frames) return;
     const size_t f = i / per_frame, r = i % per_frame;
-    const uint32_t word = packed[f * frame_words + (r >> 1)];
-    const uint32_t bits = (word >> (16 * (r & 1))) & 0xFFFFu;
+    const uint32_t word = packed[f * frame_words + r];
     uint32_t d[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint32_t nib = (bits >> (4 * q)) & 0xFu;
-        const uint32_t spread = (nib * 0x00204081u) & 0x01010101u;  // bit j -> byte j
-        d[q] = 0x40404040u | (spread << 7);
+        uint32_t t = (word >> (8 * q)) & 0xFFu;       // bit j of the byte -> bit 4 j
+        t = (t | (t << 12)) & 0x000F000Fu;
+        t = (t | (t << 6)) & 0x03030303u;
+        t = (t | (t << 3)) & 0x11111111u;
+        d[q] = 0x22222222u | (t << 3);                // the sign bit of nibble j
     }
     out[i] = make_uint4(d[0], d[1], d[2], d[3]);
 }
 
-// W: 32-bit words per packed row (the contraction length is 32 W), NT: 32-query tiles per wave,
-// kTileRows: train rows per LDS tile (a multiple of 64).
+// W: 32-bit words per packed row (the contraction length is 32 W; 64 per MFMA), NT: 32-query
+// tiles per wave, kTileRows: train rows per LDS tile (a multiple of 64).
 template <int W, int NT, int kTileRows>
 __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
-    constexpr int kRowBytes = 32 * W;
-    constexpr int kCpr = kRowBytes / 16;                 // 16-byte chunks per row
+    static_assert(W % 2 == 0, "whole 64-bit k steps");
+    constexpr int KS = W / 2;                            // k steps (MFMAs) per 32 x 32 tile
+    constexpr int kRowBytes = 16 * W;
+    constexpr int kCpr = W;                              // 16-byte chunks per row: one per word
     constexpr int kSwz = kCpr < 16 ? kCpr - 1 : 15;
     constexpr int kTileBytes = kTileRows * kRowBytes;
     constexpr int kStagePerWave = kTileRows * kCpr / 64 / kWaves;  // 1 KiB wave-instructions per wave and tile
@@ -150,21 +160,21 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
     const uint8_t* qrows = a.q_rows + (size_t)qf * a.frame_bytes;
     const uint8_t* trows = a.t_rows + (size_t)tf * a.frame_bytes;
 
-    // B operand: the negated signed bytes of this lane's queries, resident for the whole kernel.
-    // breg[n][m] holds bits 32m + 16lh .. + 15 of query q0 + wave * kQPerWave + 32n + li.
-    intx4 breg[NT][W];
+    // B operand: the negated units of this lane's queries, resident for the whole kernel.
+    // breg[n][m] holds bits 64m + 32lh .. + 31 of query q0 + wave * kQPerWave + 32n + li.
+    intx4 breg[NT][KS];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         int qi = q0 + wave * kQPerWave + 32 * n + li;
         qi = qi < nq ? qi : nq - 1;
         const intx4* src = reinterpret_cast<const intx4*>(qrows + (size_t)qi * kRowBytes);
 #pragma unroll
-        for (int m = 0; m < W; ++m) {
+        for (int m = 0; m < KS; ++m) {
             const intx4 v = src[2 * m + lh];
-            breg[n][m] = v ^ (int)0x80808080;  // +-64 -> -+64
+            breg[n][m] = v ^ (int)0x88888888;  // +-1 -> -+1
         }
     }
-    // best two per query tile, kept twice (even and odd accumulator registers) so that the
+    // best two per query tile, kept twice (even and odd accumulator pairs) so that the
     // vector ALU always has independent chains to issue from; merged at the end
     uint32_t m1[NT][2], m2[NT][2];
 #pragma unroll
@@ -179,8 +189,6 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
 
     // global -> LDS copy of one tile: LDS position p (16-byte chunks, linear) holds chunk
     // (p % kCpr) ^ (row & kSwz) of row p / kCpr; each wave instruction fills 64 positions.
-    // (Staging through registers instead lets the compiler wait for single fragment reads
-    // rather than for all outstanding ones, but measured 2 % slower.)
     auto stage = [&](int k, int buf) {
         const int tbase = t_begin + k * kTileRows;
         uint8_t* dst = lds + buf * kTileBytes;
@@ -200,78 +208,86 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
 
     // accumulator start: register r of a 32-row half tile is its train row 8(r>>2) + 4lh + (r&3);
     // it starts at 4096 * bits + the row's index in the workgroup's range.  The start values of
-    // a half tile are formed afresh (a per-lane constant + one scalar per register): a vector
+    // a half tile are formed afresh (a per-lane value + one constant per register): a vector
     // updated in place would be live across the MFMAs that start from it and cost a register
     // copy per half tile.
-    const int lane_base = 4096 * kRowBytes + 4 * lh;
+    const float lane_base = (float)(4096 * 32 * W + 4 * lh);
+    const int scale = kScale;
     __syncthreads();
 
     // Two accumulator sets, one per half of a tile.  While the matrix pipe accumulates one half
     // tile into one set, the vector ALU folds the other set (the previous half tile) into the
     // best-two lists, a slice of it after every k step, so the fold hides behind the MFMAs.
     constexpr int kGroups = 4;  // slices of a set: 4 accumulator registers of every query tile
-    intx16 acc0[NT], acc1[NT];
+    floatx16 acc0[NT], acc1[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[n][r] = acc1[n][r] = kMasked;
 
-    auto fold_group = [&](const intx16 (&acc)[NT], int gq) {
+    auto fold_group = [&](const floatx16 (&acc)[NT], int gq) {
 #pragma unroll
         for (int r = 0; r < 4; r += 2)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                top2_pair(m1[n][r >> 1], m2[n][r >> 1], (uint32_t)acc[n][4 * gq + r],
-                          (uint32_t)acc[n][4 * gq + r + 1]);
+                top2_pair(m1[n][r >> 1], m2[n][r >> 1], __float_as_uint(acc[n][4 * gq + r]),
+                          __float_as_uint(acc[n][4 * gq + r + 1]));
     };
 
     const int left = t_end - t_begin;
-    // One tile: kSteps k steps (W per 32-row half tile), the A fragments read two k steps
-    // ahead through a ring of three.  first: index of the tile's first row in the range;
-    // masked: the tile may hold rows past the range (the last tile only).
+    // One tile: kSteps k steps (KS per 32-row half tile), the A fragments read kAhead k steps
+    // ahead through a ring.  first: index of the tile's first row in the range; masked: the
+    // tile may hold rows past the range (the last tile only).
     constexpr int kHalves = kTileRows / 32;
-    constexpr int kSteps = kHalves * W;
+    constexpr int kSteps = kHalves * KS;
+    constexpr int kRing = kAhead + 1;
     const int swz = li & kSwz;                       // 32-row pieces keep row & kSwz == li & kSwz
     const int lane_off = li * kRowBytes;
     auto tile_body = [&](const uint8_t* tile, int first, bool masked) {
         const uint8_t* rowp = tile + lane_off;
         auto frag = [&](int s) {
-            const int mt = s / W, m = s % W;
+            const int mt = s / KS, m = s % KS;
             return *reinterpret_cast<const intx4*>(rowp + mt * (32 * kRowBytes) +
                                                    (((2 * m + lh) ^ swz) * 16));
         };
-        intx4 ring[3];
-        ring[0] = frag(0);
-        ring[1] = frag(1);
+        intx4 ring[kRing];
+#pragma unroll
+        for (int s = 0; s < kAhead && s < kSteps; ++s) ring[s] = frag(s);
+        const float first_base = lane_base + (float)first;
 #pragma clang loop unroll(full)
         for (int s = 0; s < kSteps; ++s) {
-            const int mt = s / W, m = s % W;
-            if (s + 2 < kSteps) ring[(s + 2) % 3] = frag(s + 2);
-            intx16 (&accC)[NT] = (mt & 1) ? acc1 : acc0;
-            const intx16 (&accF)[NT] = (mt & 1) ? acc0 : acc1;
-            intx16 start;
+            const int mt = s / KS, m = s % KS;
+            if (s + kAhead < kSteps) ring[(s + kAhead) % kRing] = frag(s + kAhead);
+            floatx16 (&accC)[NT] = (mt & 1) ? acc1 : acc0;
+            const floatx16 (&accF)[NT] = (mt & 1) ? acc0 : acc1;
+            floatx16 start;
             if (m == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    start[r] = lane_base + (first + 32 * mt + 8 * (r >> 2) + (r & 3));
+                    start[r] = first_base + (float)(32 * mt + 8 * (r >> 2) + (r & 3));
                 if (masked) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if ((start[r] & ((1 << kLocalBits) - 1)) >= left) start[r] = kMasked;
+                        if (first + 32 * mt + 8 * (r >> 2) + 4 * lh + (r & 3) >= left) start[r] = kMasked;
                 }
             }
+            const intx4 av = ring[s % kRing];
+            const intx8 a8 = {av[0], av[1], av[2], av[3], 0, 0, 0, 0};
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-                accC[n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ring[s % 3], breg[n][m],
-                                                                m == 0 ? start : accC[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) {
+                const intx4 bv = breg[n][m];
+                const intx8 b8 = {bv[0], bv[1], bv[2], bv[3], 0, 0, 0, 0};
+                // cbsz = blgp = 4: both operands E2M1; block scales 2^6 x 2^6
+                accC[n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                    a8, b8, m == 0 ? start : accC[n], 4, 4, 0, scale, 0, scale);
+            }
             // The fold of the other set starts one k step late (that set's last MFMAs were
             // issued just before this half tile) and is spread over the remaining k steps.
             if (m > 0) {
 #pragma unroll
-                for (int gi = ((m - 1) * kGroups) / (W - 1); gi < (m * kGroups) / (W - 1); ++gi)
+                for (int gi = ((m - 1) * kGroups) / (KS - 1); gi < (m * kGroups) / (KS - 1); ++gi)
                     fold_group(accF, gi);
             }
-
             // keep every k step's MFMAs and its share of the fold together: the compiler
             // otherwise gathers the whole fold in front of the MFMAs
             __builtin_amdgcn_sched_barrier(0);
@@ -289,9 +305,11 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
     for (int gi = 0; gi < kGroups; ++gi) fold_group(acc1, gi);
 
     // accumulator -> (distance << 18 | train index); the two lane halves saw different rows
-    auto to_key = [&](uint32_t v) {
+    auto to_key = [&](uint32_t bits) {
+        const float f = __uint_as_float(bits);
+        const uint32_t v = (uint32_t)f;
         const uint32_t h = v >> kLocalBits, local = v & ((1u << kLocalBits) - 1);
-        return v < kRealLimit ? (h << kIdxBits) | (uint32_t)(t_begin + (int)local) : kNoKey;
+        return f < kRealLimit ? (h << kIdxBits) | (uint32_t)(t_begin + (int)local) : kNoKey;
     };
     uint2* out = a.keys + ((size_t)problem * a.splits + split) * (size_t)a.rows_max;
 #pragma unroll
@@ -313,7 +331,7 @@ int hamming_mfma_q_per_block(int row_words) {
     switch (row_words) {
         case 4:
         case 8: return kWaves * 64;
-        case 16: return kWaves * 32;  // 64-byte rows: one query tile per wave fits the registers
+        case 16: return kWaves * 64;
         default: return 0;
     }
 }
@@ -340,12 +358,12 @@ MfmaPlan make_mfma_plan(const sfm_ctx* ctx, int row_words, int rows_max, int n_p
     return p;
 }
 
-size_t hamming_mfma_frame_bytes(int row_words, int rows) { return (size_t)rows * row_words * 32; }
+size_t hamming_mfma_frame_bytes(int row_words, int rows) { return (size_t)rows * row_words * 16; }
 
 int launch_hamming_expand(sfm_ctx* ctx, const void* packed, size_t frame_stride, int row_words,
                           int rows, int n_frames, void* d_rows) {
     if (rows <= 0 || n_frames <= 0) return SFM_OK;
-    const size_t units = (size_t)rows * row_words * 2 * n_frames;
+    const size_t units = (size_t)rows * row_words * n_frames;
     const size_t grid = (units + 255) / 256;
     if (grid > 0x7fffffffUL) return set_error(ctx, SFM_E_INVALID, "expand launch too large");
     KernelTimer timer(ctx, KID_HAMMING_EXPAND);
@@ -390,7 +408,7 @@ int launch_hamming_mfma(sfm_ctx* ctx, const MfmaPlan& plan, const void* d_q_rows
                                ctx->stream, a);
             break;
         case 16:
-            hipLaunchKernelGGL((hamming_mfma_kernel<16, 1, 64>), dim3((unsigned)grid), dim3(kThreads), 0,
+            hipLaunchKernelGGL((hamming_mfma_kernel<16, 2, 128>), dim3((unsigned)grid), dim3(kThreads), 0,
                                ctx->stream, a);
             break;
         default:
