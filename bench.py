@@ -26,15 +26,15 @@ if ROOT not in sys.path:
 
 METRIC = "matched+tracked features/sec (ms/frame pair @8k kps) at 1/2/4/8 MI355X"
 VALU_PEAK_TLANEOPS = 78.6   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
-I8_MFMA_PEAK_TOPS = 5033.0  # dense int8: 256 CU x 4 SIMD x 2048 ops/clk (32x32x32 per 32 clk) x 2.4 GHz
+FP4_MFMA_PEAK_TOPS = 10066.0  # dense 4-bit: 256 CU x 4 SIMD x 4096 ops/clk (32x32x64 per 32 clk) x 2.4 GHz
 
 
 def hamming_roofline(prof, n_directions, rows, desc_bytes, launches_note):
     """Roofline entry of whichever Hamming kernel ran.  n_directions: 2-NN problems of
     rows x rows per launch.  The algorithmic work is 2 * ceil(D/4) lane-ops per descriptor
-    pair (xor + popcount per 32-bit word); the matrix-core kernel executes it as an int8
-    contraction of 8 D multiply-adds per pair and is priced against the dense int8 MFMA peak,
-    with the lane-op rate of the same launch beside it."""
+    pair (xor + popcount per 32-bit word); the matrix-core kernel executes it as a contraction
+    of 8 D multiply-adds of 4-bit operands per pair and is priced against the dense 4-bit MFMA
+    peak, with the lane-op rate of the same launch beside it."""
     words = (desc_bytes + 3) // 4
     lane_ops = float(n_directions) * rows * rows * 2 * words
     for name in ("hamming_mfma_kernel", "hamming_pair_kernel", "hamming_knn2_kernel"):
@@ -49,10 +49,11 @@ def hamming_roofline(prof, n_directions, rows, desc_bytes, launches_note):
     if name == "hamming_mfma_kernel":
         mac_ops = float(n_directions) * rows * rows * (32 * words) * 2
         ach = mac_ops / sec / 1e12
-        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 1), "peak": I8_MFMA_PEAK_TOPS,
-                "unit": "TOP/s (int8, multiply-add = 2)", "frac": round(ach / I8_MFMA_PEAK_TOPS, 4),
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 1), "peak": FP4_MFMA_PEAK_TOPS,
+                "unit": "TOP/s (4-bit operands, multiply-add = 2)",
+                "frac": round(ach / FP4_MFMA_PEAK_TOPS, 4),
                 "avg_launch_us": round(1e6 * sec, 2),
-                "algorithmic_per_launch": f"{mac_ops:.4g} int8 ops = {launches_note} x {rows}^2 x "
+                "algorithmic_per_launch": f"{mac_ops:.4g} 4-bit ops = {launches_note} x {rows}^2 x "
                                           f"{32 * words} bits x 2 (the xor/popcount form of the same "
                                           f"launch is {lane_ops:.4g} lane-ops)",
                 "valu_equivalent": {"achieved": round(lane_rate, 2), "peak": VALU_PEAK_TLANEOPS,
