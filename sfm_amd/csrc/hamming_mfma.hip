@@ -262,9 +262,14 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
             const floatx16 (&accF)[NT] = (mt & 1) ? acc0 : acc1;
             floatx16 start;
             if (m == 0) {
+                // one v_add_f32 per register, written as asm: left to itself the compiler packs
+                // pairs of these adds into v_pk_add_f32 on misaligned register pairs and then
+                // moves all sixteen results into place
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    start[r] = first_base + (float)(32 * mt + 8 * (r >> 2) + (r & 3));
+                    asm("v_add_f32 %0, %1, %2"
+                        : "=v"(start[r])
+                        : "s"((float)(32 * mt + 8 * (r >> 2) + (r & 3))), "v"(first_base));
                 if (masked) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
