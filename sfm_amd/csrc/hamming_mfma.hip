@@ -49,7 +49,7 @@ constexpr uint32_t kEmpty = 0x7F7FFFFFu;   // tracker start (FLT_MAX), above eve
 constexpr float kMasked = 1e30f;           // accumulator start of a row past the range
 constexpr float kRealLimit = 1e20f;
 constexpr int kScale = 127 + 6;            // E8M0 block scale 2^6 of both operands
-constexpr int kAhead = 3;                  // fragment reads run this many k steps ahead
+constexpr int kAhead = 2;                  // fragment reads run this many k steps ahead
 
 struct MfmaArgs {
     const uint8_t* q_rows;   // 4-bit frames: frame f at q_rows + f * frame_bytes
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
 int hamming_mfma_q_per_block(int row_words) {
     switch (row_words) {
         case 4:
-        case 8: return kWaves * 64;
+        case 8:
         case 16: return kWaves * 64;
         default: return 0;
     }
@@ -345,7 +345,16 @@ MfmaPlan make_mfma_plan(const sfm_ctx* ctx, int row_words, int rows_max, int n_p
     MfmaPlan p{};
     p.row_words = row_words;
     p.rows_max = rows_max;
-    const int qpb = hamming_mfma_q_per_block(row_words);
+    int qpb = hamming_mfma_q_per_block(row_words);
+    p.query_tiles = 2;
+    // 32-byte rows: four query tiles per wave (1024 queries per workgroup) when that still
+    // leaves two rounds of workgroups -- more independent accumulators per wave and half the
+    // fragment reads and start values per MFMA (400 against 446 us on 32 pairs of 8192 x 8192;
+    // one such pair alone is faster with the smaller workgroups)
+    if (row_words == 8 && (long)n_problems * ((rows_max + 2 * qpb - 1) / (2 * qpb)) >= 2L * ctx->num_cus) {
+        p.query_tiles = 4;
+        qpb *= 2;
+    }
     p.qtiles = qpb ? (rows_max + qpb - 1) / qpb : 0;
     const int tiles = (rows_max + kTileUnit - 1) / kTileUnit;
     const int tiles_cap = (1 << kLocalBits) / kTileUnit;   // rows per range the keys can index
@@ -409,8 +418,12 @@ int launch_hamming_mfma(sfm_ctx* ctx, const MfmaPlan& plan, const void* d_q_rows
                                ctx->stream, a);
             break;
         case 8:
-            hipLaunchKernelGGL((hamming_mfma_kernel<8, 2, 128>), dim3((unsigned)grid), dim3(kThreads), 0,
-                               ctx->stream, a);
+            if (plan.query_tiles == 4)
+                hipLaunchKernelGGL((hamming_mfma_kernel<8, 4, 128>), dim3((unsigned)grid), dim3(kThreads),
+                                   0, ctx->stream, a);
+            else
+                hipLaunchKernelGGL((hamming_mfma_kernel<8, 2, 128>), dim3((unsigned)grid), dim3(kThreads),
+                                   0, ctx->stream, a);
             break;
         case 16:
             hipLaunchKernelGGL((hamming_mfma_kernel<16, 2, 128>), dim3((unsigned)grid), dim3(kThreads), 0,

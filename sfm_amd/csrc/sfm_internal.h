@@ -191,6 +191,7 @@ struct MfmaPlan {
     int rows_max;
     int qtiles;   // workgroups along the query rows; 0: no kernel for this row width
     int splits;   // workgroups along the train rows
+    int query_tiles;  // 32-query tiles per wave: 2 or 4
 };
 // Query rows one workgroup owns, or 0 when no matrix kernel exists for that row width.
 int hamming_mfma_q_per_block(int row_words);

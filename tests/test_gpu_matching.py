@@ -290,3 +290,49 @@ print("two-direction ok", len(got))
                          timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "two-direction ok" in out.stdout
+
+
+def test_match_pairs_many_problems(ctx, oracle):
+    """480 problems of up to 1100 rows in one launch: enough workgroups for the matrix-core
+    kernel's larger shape (four query tiles per wave, 1024 queries per workgroup), ragged
+    row counts around its tile and workgroup boundaries."""
+    import torch
+
+    from sfm_amd import capi
+
+    rng = np.random.default_rng(4242)
+    n_frames, rows, d = 16, 1100, 32
+    base = rng.integers(0, 256, size=(rows, d), dtype=np.uint8)
+    frames = []
+    for f in range(n_frames):
+        fr = base.copy()
+        flip = rng.random(size=(rows, d * 8)) < 0.05
+        fr ^= np.packbits(flip, axis=1, bitorder="little")
+        fresh = rng.random(rows) < 0.3
+        fr[fresh] = rng.integers(0, 256, size=(int(fresh.sum()), d), dtype=np.uint8)
+        frames.append(fr[rng.permutation(rows)])
+    stack = np.stack(frames)
+    counts = np.array([1100, 1025, 1024, 1023, 513, 512, 129, 128, 127, 65, 64, 33, 2, 1, 1099, 700],
+                      np.int32)
+    pairs = np.array([(i, j) for i in range(n_frames) for j in range(n_frames) if i != j], np.int32)
+    dev = torch.device("cuda:0")
+    d_desc = torch.from_numpy(stack).to(dev)
+    d_counts = torch.from_numpy(counts).to(dev)
+    d_pairs = torch.from_numpy(pairs).to(dev)
+    cap = rows
+    d_matches = torch.zeros((len(pairs), cap, 4), dtype=torch.int32, device=dev)
+    d_mc = torch.zeros(len(pairs), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.match_pairs_dev(capi.NORM_HAMMING, d_desc, n_frames, rows * d, rows, d_counts, d, d_pairs,
+                        len(pairs), 0.8, d_matches, cap, d_mc)
+    ctx.synchronize()
+    mc = d_mc.cpu().numpy()
+    m = d_matches.cpu().numpy().view(capi.DMATCH_DTYPE).reshape(len(pairs), cap)
+    total = 0
+    for p, (i, j) in enumerate(pairs):
+        want = oracle.robust_matches(oracle.NORM_HAMMING, stack[i][: counts[i]],
+                                     stack[j][: counts[j]], 0.8)
+        assert mc[p] == len(want), (i, j)
+        assert _tuples(m[p][: mc[p]]) == _tuples(want), (i, j)
+        total += len(want)
+    assert total > 2000
