@@ -152,6 +152,40 @@ def timed_steps(step, steps, warmup, world, dev, ctx, more_ctx=()):
     return max_over_ranks(dt, world, dev), prof
 
 
+LK_ITERS_PER_POINT = 12.9   # mean Lucas-Kanade iterations per point summed over the 4 levels
+                            # of the synthetic set (the CPU leg measures it; the GPU runs the
+                            # same iterations: positions and status are identical)
+
+
+def lk_roofline(prof, n_pairs, iters_per_point):
+    """Roofline entry of the tracker: vector-ALU bound.  Algorithmic work per point and level =
+    6615 + k * 2646 multiply-adds for a 21 x 21 window (441 px x (3 bilinear sums of 4 taps + 3
+    products) to set up I, dI/dx, dI/dy and the normal matrix; 441 x (4 + 2) per iteration),
+    counted as lane-ops against the vector peak.  k comes from the CPU leg of this run when it
+    ran, else from the constant above."""
+    name = "lk_track_kernel"
+    if name not in prof or not prof[name][1]:
+        return {"kernel": None, "bound": "valu", "achieved": None, "peak": VALU_PEAK_TLANEOPS,
+                "unit": "Tlane-op/s", "frac": None, "traffic": None}
+    k = iters_per_point if iters_per_point else LK_ITERS_PER_POINT
+    levels = LK_MAXLEVEL + 1
+    macs = float(n_pairs) * LK_POINTS * (levels * 6615 + k * 2646)
+    ms, n = prof[name]
+    sec = ms / n * 1e-3
+    ach = macs / sec / 1e12
+    compulsory = n_pairs * (2 * LK_W * LK_H + 21 * LK_POINTS)
+    return {"kernel": name, "bound": "valu", "achieved": round(ach, 3), "peak": VALU_PEAK_TLANEOPS,
+            "unit": "Tlane-op/s", "frac": round(ach / VALU_PEAK_TLANEOPS, 4),
+            "avg_launch_us": round(1e6 * sec, 2),
+            "algorithmic_per_launch": f"{macs:.4g} multiply-adds = {n_pairs} pairs x {LK_POINTS} points x "
+                                      f"({levels} levels x 6615 + {k:.2f} iterations x 2646)",
+            "iterations_per_point": round(k, 3),
+            "iterations_source": "cpu_baseline leg of this run" if iters_per_point else "constant",
+            "compulsory_hbm_bytes": compulsory,
+            "compulsory_hbm_GBps": round(compulsory / sec / 1e9, 1),
+            "traffic": None}
+
+
 def pmc_traffic(workload, kernels):
     """HBM bytes per launch of the first of `kernels` found in the newest committed
     profiles/rNN_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this
@@ -201,13 +235,14 @@ def cpu_baseline_framepair(desc, prevs, currs, pts):
 
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
     pyoracle.robust_matches(pyoracle.NORM_HAMMING, desc[0][:512], desc[1][:512], 0.5)  # warm-up
-    done, t0 = 0, time.perf_counter()
+    done, t0, lk_iters = 0, time.perf_counter(), 0
     while True:
         i = done % (len(desc) - 1)
         pyoracle.robust_matches(pyoracle.NORM_HAMMING, desc[i], desc[i + 1], 0.5, threads=0)
         j = done % len(prevs)
-        pyoracle.pyrlk(prevs[j], currs[j], pts[j], win=LK_WIN, max_level=LK_MAXLEVEL, crit_type=3,
-                       max_count=LK_COUNT, epsilon=LK_EPS, acc_exact=False, threads=0)
+        lk_iters += pyoracle.pyrlk(prevs[j], currs[j], pts[j], win=LK_WIN, max_level=LK_MAXLEVEL,
+                                   crit_type=3, max_count=LK_COUNT, epsilon=LK_EPS, acc_exact=False,
+                                   threads=0, return_iters=True)[-1]
         done += 1
         el = time.perf_counter() - t0
         if (el > 10.0 and done >= 2) or el > 25.0:
@@ -216,7 +251,8 @@ def cpu_baseline_framepair(desc, prevs, currs, pts):
     return {"value": round(feats / el, 1), "unit": "features/s", "cores": threads, "kind": "port",
             "sample": f"{done} frame pairs (robust matching 2x{KPS}x{KPS}x{DESC_BYTES}B + LK "
                       f"{LK_POINTS} pts {LK_W}x{LK_H}) in {el:.1f} s, restatement not OpenCV",
-            "ms_per_frame_pair": round(1e3 * el / done, 2)}
+            "ms_per_frame_pair": round(1e3 * el / done, 2),
+            "lk_iterations_per_point": round(lk_iters / (done * LK_POINTS), 3)}
 
 
 def run_framepair(args, rank, world, local):
@@ -291,6 +327,16 @@ def run_framepair(args, rank, world, local):
     if P == 32 and roof_ham["kernel"]:  # the PMC passes were taken at the default pairs per launch
         roof_ham["traffic"], roof_ham["traffic_source"] = pmc_traffic("framepair",
                                                                       [roof_ham["kernel"]])
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_framepair(desc, prevs, currs, pts)
+    roof_lk = lk_roofline(prof, P, cpu["lk_iterations_per_point"] if cpu else None)
+    if P == 32 and roof_lk["kernel"]:
+        roof_lk["traffic"], roof_lk["traffic_source"] = pmc_traffic("framepair", ["lk_track_kernel"])
+    # `roofline` describes the kernel with the largest summed device time of the step
+    roofs = {roof_ham["kernel"]: roof_ham, roof_lk["kernel"]: roof_lk}
+    roof_main = roofs.get(dominant, roof_ham)
+    roof_other = roof_lk if roof_main is roof_ham else roof_ham
     out = {
         "metric": METRIC, "value": round(value, 1), "unit": "features/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -305,7 +351,8 @@ def run_framepair(args, rank, world, local):
                    "streams": "matching and tracking on two HIP streams" if args.overlap else "one"},
         "ms_per_frame_pair": round(1e3 * dt / args.steps / P, 4),
         "dominant_kernel": dominant,
-        "roofline": roof_ham,
+        "roofline": roof_main,
+        "roofline_second_kernel": roof_other,
         "kernels": {k: kernel_line(prof, k) for k in sorted(prof)},
         "check": {"cross_checked_matches_per_step": matched, "tracked_per_step": tracked,
                   "gathered_matches": gathered.get("n")},
@@ -313,8 +360,8 @@ def run_framepair(args, rank, world, local):
     if lk_n:
         out["lk_track"] = {"avg_launch_us": round(1e3 * lk_ms / lk_n, 2),
                            "points_per_s": round(P * LK_POINTS / (lk_ms / lk_n * 1e-3), 1)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_framepair(desc, prevs, currs, pts)
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
     if ctx_lk is not ctx:
         ctx_lk.close()
