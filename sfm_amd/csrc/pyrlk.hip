@@ -131,18 +131,29 @@ __device__ __forceinline__ uint32_t pyr_down_px(const uint8_t* src, int SS, int 
 // Four horizontally adjacent pyrDown outputs (x .. x+3, row ry, all inside the level) as
 // packed bytes.  Output i takes the five source bytes 2i .. 2i+4 of a row with weights
 // 1 4 6 4 1: a byte dot product over four of them plus a second one that picks the fifth.
+// kAligned: x is a multiple of 4 (groups inside the image); mirrored border groups are not.
+template <bool kAligned>
 __device__ __forceinline__ uint32_t pyr_down_quad(const uint8_t* src, int SS, int x, int ry) {
     constexpr uint32_t kW = 0x04060401u;                      // weights of bytes 0..3
     constexpr uint32_t kE0 = 0x00000001u, kE2 = 0x00010000u;  // byte 0 / byte 2 alone
     uint32_t col[4] = {128u, 128u, 128u, 128u};               // rounding of the final >> 8
-    // source columns 2x-2 .. 2x+8 of rows 2ry-2 .. 2ry+2
-    const uint8_t* s = src + (ptrdiff_t)(2 * ry - 2) * SS + (2 * x - 2);
+    // source columns 2x-2 .. 2x+8 of rows 2ry-2 .. 2ry+2, read as four aligned dwords from
+    // column 2x-4 (x is a multiple of 4 and rows are 16-byte aligned; a load at 2x-2 would be
+    // a misaligned one)
+    const uint8_t* s = src + (ptrdiff_t)(2 * ry - 2) * SS + (2 * x - 4);
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        uint32_t q[4];
-        __builtin_memcpy(q, s + (ptrdiff_t)k * SS, 16);
-        const uint32_t m01 = __builtin_amdgcn_alignbyte(q[1], q[0], 2);  // bytes 2..5
-        const uint32_t m12 = __builtin_amdgcn_alignbyte(q[2], q[1], 2);  // bytes 6..9
+        uint4 d;
+        if (kAligned)
+            d = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(s + (ptrdiff_t)k * SS, 4));
+        else
+            __builtin_memcpy(&d, s + (ptrdiff_t)k * SS, 16);
+        uint32_t q[3];
+        q[0] = __builtin_amdgcn_alignbyte(d.y, d.x, 2);   // columns 2x-2 .. 2x+1
+        q[1] = __builtin_amdgcn_alignbyte(d.z, d.y, 2);   // columns 2x+2 .. 2x+5
+        q[2] = __builtin_amdgcn_alignbyte(d.w, d.z, 2);   // columns 2x+6 .. 2x+9
+        const uint32_t m01 = d.y;                         // columns 2x .. 2x+3
+        const uint32_t m12 = d.z;                         // columns 2x+4 .. 2x+7
         const uint32_t h0 = __builtin_amdgcn_udot4(q[0], kW, __builtin_amdgcn_udot4(q[1], kE0, 0u, false), false);
         const uint32_t h1 = __builtin_amdgcn_udot4(m01, kW, __builtin_amdgcn_udot4(q[1], kE2, 0u, false), false);
         const uint32_t h2 = __builtin_amdgcn_udot4(q[1], kW, __builtin_amdgcn_udot4(q[2], kE0, 0u, false), false);
@@ -179,9 +190,9 @@ __global__ void lk_pyr_down_kernel(LkGeom g, int level, uint8_t* __restrict__ py
         const int m = x + 4 <= 0 ? -x - 3 : 2 * (w - 1) - x - 3;  // first column of the mirrored group
         uint32_t v = 0;
         if (x >= 0 && x + 4 <= w) {
-            v = pyr_down_quad(src, SS, x, ry);
+            v = pyr_down_quad<true>(src, SS, x, ry);
         } else if ((x + 4 <= 0 || (x >= w && x + 4 <= w + g.bw)) && m >= 0 && m + 4 <= w) {
-            v = __builtin_bswap32(pyr_down_quad(src, SS, m, ry));
+            v = __builtin_bswap32(pyr_down_quad<false>(src, SS, m, ry));
         } else {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
