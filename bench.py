@@ -72,6 +72,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 KPS = 8192
 DESC_BYTES = 32
 LK_POINTS = 5000
+DEFAULT_PAIRS = 64   # frame pairs per rank and step (the tracking configuration is batched by 64)
 LK_W, LK_H = 1280, 720
 LK_WIN, LK_MAXLEVEL, LK_COUNT, LK_EPS = (21, 21), 3, 30, 0.01
 
@@ -82,7 +83,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="framepair", choices=["framepair", "c3", "c4", "c5", "f1", "f2", "f3", "vo"])
-    ap.add_argument("--pairs", type=int, default=32, help="frame pairs per rank and step")
+    ap.add_argument("--pairs", type=int, default=None,
+                    help="frame pairs (problems, frames) per rank and step; default 64 for the "
+                         "frame-pair workload, 32 for f1 / f2 / f3 / vo")
     ap.add_argument("--frames", type=int, default=512, help="c5: frames in the window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
@@ -261,7 +264,7 @@ def run_framepair(args, rank, world, local):
     from sfm_amd import allpairs, capi, synth
 
     dev = torch.device("cuda", local)
-    P = args.pairs
+    P = (args.pairs or DEFAULT_PAIRS)
     ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
     # Matching and tracking of a frame pair are independent: with --overlap the tracking
     # kernels go to a second stream (own context) and run concurrently with matching.
@@ -324,14 +327,14 @@ def run_framepair(args, rank, world, local):
     dominant = max(prof.items(), key=lambda kv: kv[1][0])[0]
     lk_ms, lk_n = prof.get("lk_track_kernel", (0.0, 0))
     roof_ham = hamming_roofline(prof, 2 * P, KPS, DESC_BYTES, f"2 dirs x {P} pairs")
-    if P == 32 and roof_ham["kernel"]:  # the PMC passes were taken at the default pairs per launch
+    if P == DEFAULT_PAIRS and roof_ham["kernel"]:  # the PMC passes were taken at the default pairs per launch
         roof_ham["traffic"], roof_ham["traffic_source"] = pmc_traffic("framepair",
                                                                       [roof_ham["kernel"]])
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_framepair(desc, prevs, currs, pts)
     roof_lk = lk_roofline(prof, P, cpu["lk_iterations_per_point"] if cpu else None)
-    if P == 32 and roof_lk["kernel"]:
+    if P == DEFAULT_PAIRS and roof_lk["kernel"]:
         roof_lk["traffic"], roof_lk["traffic_source"] = pmc_traffic("framepair", ["lk_track_kernel"])
     # `roofline` describes the kernel with the largest summed device time of the step
     roofs = {roof_ham["kernel"]: roof_ham, roof_lk["kernel"]: roof_lk}
@@ -587,7 +590,7 @@ def run_f1(args, rank, world, local):
     from sfm_amd import capi
 
     dev = torch.device("cuda", local)
-    P = args.pairs
+    P = (args.pairs or 32)
     ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
     desc, kps = f1_inputs(P, seed=777 + rank)
     pairs = np.stack([2 * np.arange(P), 2 * np.arange(P) + 1], 1).astype(np.int32)
@@ -683,7 +686,7 @@ def run_f2(args, rank, world, local):
     from sfm_amd import capi, synth
 
     dev = torch.device("cuda", local)
-    P, N = args.pairs, LK_POINTS
+    P, N = (args.pairs or 32), LK_POINTS
     ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
     rng = np.random.default_rng(4242 + rank)
     pts1 = np.zeros((P, N, 2), np.float32)
@@ -772,7 +775,7 @@ def run_f3(args, rank, world, local):
     from sfm_amd import capi, synth
 
     dev = torch.device("cuda", local)
-    P = args.pairs
+    P = (args.pairs or 32)
     MAXC, QUAL, MIND = 2000, 0.01, 10.0
     ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
     n_tex = min(4, P)
@@ -848,7 +851,7 @@ def run_vo(args, rank, world, local):
     from sfm_amd import capi, synth
 
     dev = torch.device("cuda", local)
-    P, MAXC = args.pairs, 2000
+    P, MAXC = (args.pairs or 32), 2000
     ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
     # frames of a fronto-parallel textured plane under a sideways camera move with some roll:
     # 24-36 px of image motion, i.e. a depth of about 30 baselines (recoverPose discards
