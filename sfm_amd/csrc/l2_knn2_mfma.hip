@@ -18,13 +18,13 @@
 //      accumulators are initialised with ||t||^2 straight from LDS, so the
 //      accumulator is the ranking key when the k-loop ends.  Every (lane half,
 //      train split) keeps its own best two, which are written out as candidates.
-//   2. Re-score pass.  For every candidate the squared distance is recomputed
-//      as the sequential float sum  d += (a-b)*(a-b)  (the scalar order of
-//      OpenCV's normL2Sqr), the square root is taken for NORM_L2, and the best
-//      two are chosen by (distance, train index).  The results therefore do not
-//      depend on the rounding of the MFMA form, unless three or more train rows
-//      of one candidate list lie within fp32 rounding of the second-best
-//      distance.
+//   2. Re-score pass.  For the eight candidates of a query with the smallest ranking
+//      keys the squared distance is recomputed as the sequential float sum
+//      d += (a-b)*(a-b)  (the scalar order of OpenCV's normL2Sqr), the square root
+//      is taken for NORM_L2, and the best two are chosen by (distance, train index).
+//      The results therefore do not depend on the rounding of the MFMA form, unless
+//      three or more train rows of one candidate list, or more than six candidates
+//      of a query, lie within fp32 rounding of the second-best distance.
 #include <cfloat>
 
 #include "sfm_internal.h"
@@ -58,6 +58,7 @@ struct L2Args {
     int n_groups;
     int qtiles, splits, blocks_per_group;
     int32_t* cand;  // [problem][split][rows_cap][4]
+    float* cand_key;  // the candidates' ranking keys ||t||^2 - 2 q.t, same layout
 };
 
 __device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
@@ -251,13 +252,17 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
         }
     }
 
-    int32_t* cand = a.cand + (((size_t)problem * a.splits + split) * a.rows_cap) * 4;
+    const size_t cbase = (((size_t)problem * a.splits + split) * a.rows_cap) * 4;
+    int32_t* cand = a.cand + cbase;
+    float* ckey = a.cand_key + cbase;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int qi = q0 + wave * kQPerWave + 32 * n + li;
         if (qi < nq) {
             cand[(size_t)qi * 4 + 2 * lh] = bidx0[n];
             cand[(size_t)qi * 4 + 2 * lh + 1] = bidx1[n];
+            ckey[(size_t)qi * 4 + 2 * lh] = best0[n];
+            ckey[(size_t)qi * 4 + 2 * lh + 1] = best1[n];
         }
     }
 }
@@ -291,6 +296,7 @@ struct RescoreArgs {
     int K, dim;
     int squared;
     const int32_t* cand;
+    const float* cand_key;
     int32_t* knn_idx;  // [problem][rows_cap][2]
     float* knn_dist;
 };
@@ -304,7 +310,13 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return v;
 }
 
-// One wave per (problem, query): lane c re-scores candidate c.
+constexpr int kRescored = 8;  // candidates per query whose distance is recomputed
+
+// One wave per (problem, query): lane c holds candidate c of the query (four per train
+// split).  The kRescored candidates with the smallest ranking keys are re-scored; the rest
+// cannot be among the two nearest unless more than kRescored - 2 candidates lie within the
+// rounding of the MFMA form of the second-best distance.  (Re-scoring all of them gathered
+// 64 train rows per query: 655 MB for 20 000 queries, most of this kernel's time.)
 __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
     const int lane = threadIdx.x & 63;
     const int problem = blockIdx.y;
@@ -322,10 +334,31 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
     const float* trows = a.t_base + (size_t)tf * a.frame_floats;
     const int ncand = a.splits * 4;
     int ti = -1;
+    unsigned long long pre = ~0ull;  // (orderable ranking key, train index)
     if (lane < ncand) {
         const int split = lane >> 2, slot = lane & 3;
-        ti = a.cand[((((size_t)problem * a.splits + split) * a.rows_cap) + q) * 4 + slot];
+        const size_t o = ((((size_t)problem * a.splits + split) * a.rows_cap) + q) * 4 + slot;
+        ti = a.cand[o];
+        if (ti >= 0) {
+            const unsigned u = __float_as_uint(a.cand_key[o]);
+            const unsigned ord = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+            pre = ((unsigned long long)ord << 32) | (unsigned)ti;
+        }
     }
+    bool chosen = ncand <= kRescored;
+    if (!chosen) {
+        unsigned long long rest = pre;
+#pragma unroll 1
+        for (int r = 0; r < kRescored; ++r) {
+            const unsigned long long m = wave_min_u64(rest);
+            if (m == ~0ull) break;  // wave-uniform
+            if (rest == m) {
+                chosen = true;
+                rest = ~0ull;
+            }
+        }
+    }
+    if (!chosen) ti = -1;
     unsigned long long key = ~0ull;
     if (ti >= 0) {
         // Scalar order of OpenCV's normL2Sqr; rows are zero-padded to K floats and
@@ -410,7 +443,7 @@ int launch_candidates(sfm_ctx* ctx, const L2Args& a, long grid) {
 int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const float* q_base,
                   const float* t_base, const float* t_norms, size_t frame_floats, int rows_cap,
                   const int32_t* d_counts, int nq_uniform, int nt_uniform, const int32_t* d_pairs,
-                  int n_problems, int32_t* cand, int32_t* knn_idx, float* knn_dist) {
+                  int n_problems, int32_t* cand, float* cand_key, int32_t* knn_idx, float* knn_dist) {
     L2Args a{};
     a.q_base = q_base;
     a.t_base = t_base;
@@ -426,6 +459,7 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     a.splits = plan.splits;
     a.blocks_per_group = (d_pairs ? 2 : 1) * plan.qtiles * plan.splits;
     a.cand = cand;
+    a.cand_key = cand_key;
     const long grid = (long)a.n_groups * a.blocks_per_group;
     if (grid <= 0) return SFM_OK;
     if (grid > 0x7fffffffL) return set_error(ctx, SFM_E_INVALID, "knn launch too large");
@@ -450,6 +484,7 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     r.dim = dim;
     r.squared = squared;
     r.cand = cand;
+    r.cand_key = cand_key;
     r.knn_idx = knn_idx;
     r.knn_dist = knn_dist;
     const int nq_max = d_counts ? rows_cap : nq_uniform;
@@ -490,6 +525,7 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
     sz.take<float>((size_t)rows_cap);
     sz.take<float>((size_t)rows_cap);
     sz.take<int32_t>((size_t)plan.splits * rows_cap * 4);
+    sz.take<float>((size_t)plan.splits * rows_cap * 4);
     sz.take<int32_t>((size_t)rows_cap * 2);
     sz.take<float>((size_t)rows_cap * 2);
     void* ws;
@@ -500,12 +536,13 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
     float* qn = c.take<float>((size_t)rows_cap);
     float* tn = c.take<float>((size_t)rows_cap);
     int32_t* cand = c.take<int32_t>((size_t)plan.splits * rows_cap * 4);
+    float* ckey = c.take<float>((size_t)plan.splits * rows_cap * 4);
     int32_t* kidx = c.take<int32_t>((size_t)rows_cap * 2);
     float* kdist = c.take<float>((size_t)rows_cap * 2);
     SFM_RETURN_IF(l2_pack(ctx, d_q, nq, q_stride, dim, qp, K, qn));
     SFM_RETURN_IF(l2_pack(ctx, d_t, nt, t_stride, dim, tp, K, tn));
     SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, qp, tp, tn, 0, rows_cap, nullptr, nq, nt,
-                                nullptr, 1, cand, kidx, kdist));
+                                nullptr, 1, cand, ckey, kidx, kdist));
     SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, kidx, sizeof(int32_t) * 2 * nq, hipMemcpyDeviceToDevice,
                                       ctx->stream));
     SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_dist, kdist, sizeof(float) * 2 * nq, hipMemcpyDeviceToDevice,
@@ -518,6 +555,7 @@ struct L2PairBuffers {
     float* packed;
     float* norms;
     int32_t* cand;
+    float* cand_key;
     int32_t* kidx;
     float* kdist;
     int32_t* best;
@@ -529,6 +567,7 @@ void l2_pairs_carve(Carver& c, const L2Plan& plan, int n_frames, int rows, int n
     b->norms = c.take<float>((size_t)n_frames * rows);
     const size_t nprob = 2 * (size_t)n_pairs;
     b->cand = c.take<int32_t>(nprob * plan.splits * rows * 4);
+    b->cand_key = c.take<float>(nprob * plan.splits * rows * 4);
     b->kidx = c.take<int32_t>(nprob * rows * 2);
     b->kdist = c.take<float>(nprob * rows * 2);
     b->best = c.take<int32_t>(nprob * rows);
@@ -577,8 +616,8 @@ int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_fr
         const int32_t* pairs = d_pairs + 2 * (size_t)p0;
         SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, b.packed, b.packed, b.norms,
                                     (size_t)rows_per_frame * plan.K, rows_per_frame, d_counts,
-                                    rows_per_frame, rows_per_frame, pairs, 2 * np, b.cand, b.kidx,
-                                    b.kdist));
+                                    rows_per_frame, rows_per_frame, pairs, 2 * np, b.cand, b.cand_key,
+                                    b.kidx, b.kdist));
         SFM_RETURN_IF(launch_ratio_cross_knn(ctx, b.kidx, b.kdist, rows_per_frame, d_counts,
                                              rows_per_frame, pairs, np, ratio, b.best, b.best_dist,
                                              d_matches + (size_t)p0 * cap, cap,
