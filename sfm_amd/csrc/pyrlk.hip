@@ -206,55 +206,70 @@ __global__ void lk_pyr_down_kernel(LkGeom g, int level, uint8_t* __restrict__ py
 }
 
 // Scharr derivative of the previous image, all levels in one launch (blockIdx.y = level,
-// blockIdx.z = pair); zero in the border.  One thread writes four adjacent pixels (16 bytes)
-// from three aligned dwords of each of the three source rows.
+// blockIdx.z = pair); zero in the border.  One thread writes sixteen adjacent pixels (four
+// 16-byte stores) from one aligned 16-byte load and its two neighbouring dwords of each of
+// the three source rows.
 __global__ void lk_scharr_kernel(LkGeom g, const uint8_t* __restrict__ pyr_prev,
                                  uint32_t* __restrict__ deriv) {
     const int level = blockIdx.y, pair = blockIdx.z;
     const uint8_t* src = pyr_prev + (size_t)pair * g.block + g.img_off[level];
     uint32_t* dst = deriv + (size_t)pair * g.block + g.img_off[level];
     const int S = g.stride[level], w = g.w[level], h = g.h[level];
-    const int per_row = S / 4, total = per_row * (h + 2 * g.bh);
+    const int per_row = S / 16, total = per_row * (h + 2 * g.bh);
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         int yy, xg;
         divmod_small(t, per_row, yy, xg);
-        const int y = yy - g.bh, xi = xg * 4;
-        const int x0 = xi - g.bw;  // image column of the first of the four pixels
-        uint32_t out[4] = {0, 0, 0, 0};
-        if (y >= 0 && y < h && x0 + 3 >= 0 && x0 < w) {
-            // padded columns xi-1 .. xi+4 of rows y-1, y, y+1 (lkpyramid.cpp calcSharrDeriv:
-            // vertical pass first, then the horizontal one)
-            int sv[6], dv[6];
+        const int y = yy - g.bh, xi = xg * 16;
+        const int x0 = xi - g.bw;  // image column of the first of the sixteen pixels
+        uint32_t* drow = dst + (ptrdiff_t)y * S - g.bw;
+        if (!(y >= 0 && y < h && x0 + 15 >= 0 && x0 < w)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint4*>(drow + xi + 4 * q) = make_uint4(0, 0, 0, 0);
+            continue;
+        }
+        // padded columns xi-1 .. xi+16 of rows y-1, y, y+1 (lkpyramid.cpp calcSharrDeriv:
+        // vertical pass first, then the horizontal one)
+        int sv[18], dv[18];
+        {
+            uint32_t px[3][18];
             const uint8_t* r1 = src + (ptrdiff_t)y * S + x0;
-            uint32_t px[3][6];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const uint8_t* row = r1 + (ptrdiff_t)(r - 1) * S;
                 const uint32_t a = xi >= 4 ? *reinterpret_cast<const uint32_t*>(row - 4) : 0u;
-                const uint32_t b = *reinterpret_cast<const uint32_t*>(row);
-                const uint32_t c = xi + 4 < S ? *reinterpret_cast<const uint32_t*>(row + 4) : 0u;
+                const uint4 b = *reinterpret_cast<const uint4*>(row);
+                const uint32_t c = xi + 16 < S ? *reinterpret_cast<const uint32_t*>(row + 16) : 0u;
                 px[r][0] = a >> 24;
-                px[r][1] = b & 0xFF;
-                px[r][2] = (b >> 8) & 0xFF;
-                px[r][3] = (b >> 16) & 0xFF;
-                px[r][4] = b >> 24;
-                px[r][5] = c & 0xFF;
+                const uint32_t bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    px[r][1 + 4 * q] = bw[q] & 0xFF;
+                    px[r][2 + 4 * q] = (bw[q] >> 8) & 0xFF;
+                    px[r][3 + 4 * q] = (bw[q] >> 16) & 0xFF;
+                    px[r][4 + 4 * q] = bw[q] >> 24;
+                }
+                px[r][17] = c & 0xFF;
             }
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
+            for (int k = 0; k < 18; ++k) {
                 sv[k] = (int)(px[0][k] + px[2][k]) * 3 + (int)px[1][k] * 10;
                 dv[k] = (int)px[2][k] - (int)px[0][k];
             }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t out[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int ix = sv[i + 2] - sv[i];
-                const int iy = (dv[i + 2] + dv[i]) * 3 + dv[i + 1] * 10;
-                const bool in = (unsigned)(x0 + i) < (unsigned)w;
+                const int j = 4 * q + i;
+                const int ix = sv[j + 2] - sv[j];
+                const int iy = (dv[j + 2] + dv[j]) * 3 + dv[j + 1] * 10;
+                const bool in = (unsigned)(x0 + j) < (unsigned)w;
                 out[i] = in ? (((uint32_t)ix & 0xFFFFu) | ((uint32_t)iy << 16)) : 0u;
             }
+            *reinterpret_cast<uint4*>(drow + xi + 4 * q) = make_uint4(out[0], out[1], out[2], out[3]);
         }
-        uint32_t* drow = dst + (ptrdiff_t)y * S - g.bw;
-        *reinterpret_cast<uint4*>(drow + xi) = make_uint4(out[0], out[1], out[2], out[3]);
     }
 }
 
@@ -957,7 +972,7 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     }
     {
         const int S = g.stride[0];
-        const dim3 grid(((S / 4) * (g.h[0] + 2 * g.bh) + 255) / 256, g.levels + 1, n_pairs);
+        const dim3 grid(((S / 16) * (g.h[0] + 2 * g.bh) + 255) / 256, g.levels + 1, n_pairs);
         KernelTimer timer(ctx, KID_LK_SCHARR);
         hipLaunchKernelGGL(lk_scharr_kernel, grid, blk, 0, ctx->stream, g, bufs.pyr_prev, bufs.deriv);
         SFM_HIP_CHECK(ctx, hipGetLastError());
