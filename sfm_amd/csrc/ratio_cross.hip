@@ -33,6 +33,7 @@ struct CrossArgs {
     int n_curr_uniform;
     const int32_t* pairs;
     float ratio;
+    int direct;         // 1: one part per direction -- the cross-check reads the keys itself
     int32_t* best;      // [2*n_pairs][rows_max]: ratio-passing neighbour or -1
     float* best_dist;   // [2*n_pairs][rows_max]
     sfm_dmatch* matches;
@@ -102,15 +103,38 @@ __global__ __launch_bounds__(kThreads) void ratio_cross_kernel(CrossArgs a) {
     const int32_t* fwd = a.best + (2 * (size_t)pair) * a.rows_max;
     const int32_t* bwd = fwd + a.rows_max;
     const float* fwd_dist = a.best_dist + (2 * (size_t)pair) * a.rows_max;
+    // direct mode: the single part of each direction, (key of the nearest, key of the second)
+    const uint2* kf = a.direct ? a.keys_dir[0] + (size_t)pair * a.pair_stride_dir[0] : nullptr;
+    const uint2* kb = a.direct ? a.keys_dir[1] + (size_t)pair * a.pair_stride_dir[1] : nullptr;
+    const uint32_t mask = (1u << kIdxBits) - 1;
+    // feature_processing.cpp:127 on a key pair: float * float, strict <; nt >= 2 rows
+    auto passes = [&](uint2 k, int nt) {
+        return nt >= 2 && k.y != kNoKey &&
+               (float)(k.x >> kIdxBits) < a.ratio * (float)(k.y >> kIdxBits);
+    };
     const int lane = tid & 63, wave = tid >> 6;
     int running = 0;
     for (int c0 = 0; c0 < n_curr; c0 += kThreads) {
         const int c = c0 + tid;
         int p = -1;
         bool ok = false;
+        float dist = 0.f;
         if (c < n_curr) {
-            p = bwd[c];
-            ok = p >= 0 && p < n_prev && fwd[p] == c;
+            if (a.direct) {
+                const uint2 b = kb[c];
+                if (passes(b, n_prev)) {
+                    p = (int)(b.x & mask);
+                    if (p < n_prev) {
+                        const uint2 f = kf[p];
+                        ok = passes(f, n_curr) && (int)(f.x & mask) == c;
+                        dist = (float)(f.x >> kIdxBits);
+                    }
+                }
+            } else {
+                p = bwd[c];
+                ok = p >= 0 && p < n_prev && fwd[p] == c;
+                if (ok) dist = fwd_dist[p];
+            }
         }
         const unsigned long long ballot = __ballot(ok);
         const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
@@ -130,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void ratio_cross_kernel(CrossArgs a) {
                 m.queryIdx = p;
                 m.trainIdx = c;
                 m.imgIdx = 0;
-                m.distance = fwd_dist[p];
+                m.distance = dist;
                 a.matches[(size_t)pair * a.cap + pos] = m;
             }
         }
@@ -208,7 +232,8 @@ int launch_ratio_cross(sfm_ctx* ctx, const KnnPlan& plan, const uint32_t* d_keys
     a.matches = d_matches;
     a.cap = cap;
     a.match_counts = d_match_counts;
-    {
+    a.direct = plan.splits == 1;  // nothing to merge: the cross-check reads the keys itself
+    if (!a.direct) {
         KernelTimer timer(ctx, KID_MERGE_RATIO);
         hipLaunchKernelGGL(merge_ratio_kernel, dim3((a.rows_max + 255) / 256, 2 * n_pairs), dim3(256),
                            0, ctx->stream, a);
