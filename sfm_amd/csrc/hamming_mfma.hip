@@ -257,6 +257,10 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
 #pragma clang loop unroll(full)
         for (int s = 0; s < kSteps; ++s) {
             const int mt = s / KS, m = s % KS;
+            // Half way through the tile the copy of the next one has landed: retire it, so that
+            // for the rest of the tile the compiler waits for single fragment reads (while a
+            // global -> LDS load is in flight it waits for all outstanding LDS reads at once)
+            if (s == kSteps / 2) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
             if (s + kAhead < kSteps) ring[(s + kAhead) % kRing] = frag(s + kAhead);
             floatx16 (&accC)[NT] = (mt & 1) ? acc1 : acc0;
             const floatx16 (&accF)[NT] = (mt & 1) ? acc0 : acc1;
