@@ -30,7 +30,6 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
-constexpr int kIdxBits = 18;  // also the literal in make_key
 
 struct PairArgs {
     const uint32_t* base;      // packed descriptor frames
@@ -64,7 +63,8 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
 }
 
 // (d << 18) | idx in one instruction (the compiler shares the shift between the row key
-// and the column key and then needs three).
+// and the column key and then needs three).  18 = the index bits of the keys the merge
+// kernels read.
 __device__ __forceinline__ uint32_t make_key(uint32_t d, uint32_t idx) {
     uint32_t r;
     asm("v_lshl_or_b32 %0, %1, 18, %2" : "=v"(r) : "v"(d), "v"(idx));
