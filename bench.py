@@ -92,17 +92,24 @@ def parse():
                     help="framepair: tracking on a second HIP stream, concurrent with matching "
                          "(+4 %% throughput; per-kernel event times then include the overlap, so "
                          "the default keeps one stream and clean kernel timings)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="framepair with one rank: run the RCCL all-gather of the match lists anyway "
+                         "(a one-rank process group), to exercise that path on a single GPU")
     return ap.parse_args()
 
 
-def dist_setup(n_gpus):
+def dist_setup(n_gpus, force_group=False):
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or force_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
@@ -300,7 +307,7 @@ def run_framepair(args, rank, world, local):
     # N > 1: every rank matches its own pairs, then all ranks exchange their match lists
     # (fixed-capacity buffers + counts, no host round trip); the collective is asynchronous
     # and overlaps the tracking kernels of the same step.
-    gather = allpairs.PaddedGather(P, cap, world, dev) if world > 1 else None
+    gather = allpairs.PaddedGather(P, cap, world, dev) if world > 1 or args.force_gather else None
     gathered = {}
 
     def step():
@@ -946,12 +953,12 @@ def run_vo(args, rank, world, local):
 
 def main():
     args = parse()
-    rank, world, local = dist_setup(args.gpus)
+    rank, world, local = dist_setup(args.gpus, args.force_gather)
     run = {"framepair": run_framepair, "c3": run_c3, "c4": run_c4, "c5": run_c5, "f1": run_f1, "f2": run_f2, "f3": run_f3, "vo": run_vo}[args.workload]
     out = run(args, rank, world, local)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_gather:
         import torch.distributed as dist
 
         dist.barrier()
