@@ -200,3 +200,29 @@ def test_padded_gather_gloo_world2(tmp_path):
              for r in range(2)]
     for p in procs:
         assert p.wait(timeout=240) == 0
+
+
+def test_bench_roofline_entries():
+    """The roofline entries bench.py derives from per-kernel times: the contraction count of
+    the matrix-core kernel, the lane-op count of the scalar kernels and the tracker's
+    multiply-add count, each divided by the launch time it was given."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    rows, d = 8192, 32
+    prof = {"hamming_mfma_kernel": (8.0, 20), "lk_track_kernel": (12.0, 20)}
+    r = bench.hamming_roofline(prof, 64, rows, d, "2 dirs x 32 pairs")
+    assert r["kernel"] == "hamming_mfma_kernel" and r["bound"] == "mfma"
+    ops = 64 * rows * rows * 256 * 2
+    assert abs(r["achieved"] - ops / 400e-6 / 1e12) < 1.0
+    assert abs(r["frac"] - r["achieved"] / bench.FP4_MFMA_PEAK_TOPS) < 1e-3
+    lane_ops = 64 * rows * rows * 16
+    assert abs(r["valu_equivalent"]["achieved"] - lane_ops / 400e-6 / 1e12) < 0.1
+    r = bench.hamming_roofline({"hamming_pair_kernel": (25.0, 20)}, 64, rows, d, "x")
+    assert r["bound"] == "valu" and abs(r["achieved"] - lane_ops / 1250e-6 / 1e12) < 0.01
+    assert bench.hamming_roofline({}, 64, rows, d, "x")["kernel"] is None
+    lk = bench.lk_roofline(prof, 32, 12.5)
+    macs = 32 * bench.LK_POINTS * (4 * 6615 + 12.5 * 2646)
+    assert lk["kernel"] == "lk_track_kernel" and abs(lk["achieved"] - macs / 600e-6 / 1e12) < 0.01
+    assert lk["iterations_source"].startswith("cpu_baseline")
+    assert bench.lk_roofline(prof, 32, None)["iterations_per_point"] == bench.LK_ITERS_PER_POINT
