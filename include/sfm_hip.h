@@ -207,6 +207,23 @@ int sfm_triangulate_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
                         float min_dist, float max_dist, float max_proj_err, double* d_X,
                         uint8_t* d_rgb, uint8_t* d_mask, double* d_err);
 
+/* sfm_triangulate_dev for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc); it has no counterpart in the
+ * reference.  Same arguments, same kernels and bit-identical results, but the lists of deferred
+ * points live in a fixed array in the library's device image (about 4 MiB, held by every GPU the
+ * library runs on until the process ends) instead of the context's grow-only workspace, and
+ * the call makes no hipMalloc / hipFree and creates no events (it is not covered by
+ * sfm_ctx_set_profiling).  n may be at most sfm_triangulate_noalloc_max_points() (2^20); more
+ * is rejected with SFM_E_INVALID.  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU (two contexts / streams) race; calls on one stream are safe. */
+int sfm_triangulate_noalloc_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
+                                const double* curr_pose, const double* R, const double* t,
+                                const float* d_prev_pts, const float* d_curr_pts, int n,
+                                const uint8_t* d_bgr, int img_w, int img_h, size_t img_stride,
+                                float min_dist, float max_dist, float max_proj_err, double* d_X,
+                                uint8_t* d_rgb, uint8_t* d_mask, double* d_err);
+int sfm_triangulate_noalloc_max_points(void);
+
 /* Device-resident hand-off from matching to triangulation: correspondence i is
  * (prev key point d_matches[i].queryIdx, curr key point d_matches[i].trainIdx), i.e. the
  * gather the reference does on the host after the cross-check (Source Files/

@@ -35,6 +35,7 @@ EXPORTS = [
     "sfm_match_pairs_dev", "sfm_match_pairs_workspace",
     "sfm_pyrlk", "sfm_pyrlk_batch_dev", "sfm_pyrlk_workspace",
     "sfm_triangulate", "sfm_triangulate_dev", "sfm_triangulate_matches_dev",
+    "sfm_triangulate_noalloc_dev", "sfm_triangulate_noalloc_max_points",
     "sfm_fundamental", "sfm_fundamental_dev", "sfm_fundamental_workspace",
     "sfm_epipolar_filter_pairs_dev", "sfm_epipolar_filter_pairs_workspace",
     "sfm_good_features", "sfm_good_features_dev", "sfm_good_features_workspace",
@@ -292,6 +293,17 @@ class Context:
                         d_mask, d_err=None):
         K, prev_pose, curr_pose, R, t = self._mats(K, prev_pose, curr_pose, R, t)
         self.check(lib().sfm_triangulate_dev(
+            self._h, _ptr(K), _ptr(prev_pose), _ptr(curr_pose), _ptr(R), _ptr(t),
+            _ptr(d_prev_pts), _ptr(d_curr_pts), C.c_int(n), _ptr(d_bgr), C.c_int(img_w),
+            C.c_int(img_h), C.c_size_t(img_stride), C.c_float(min_dist), C.c_float(max_dist),
+            C.c_float(max_proj_err), _ptr(d_X), _ptr(d_rgb), _ptr(d_mask), _ptr(d_err)))
+
+    def triangulate_noalloc_dev(self, K, prev_pose, curr_pose, R, t, d_prev_pts, d_curr_pts, n, d_bgr,
+                                img_w, img_h, img_stride, min_dist, max_dist, max_proj_err, d_X, d_rgb,
+                                d_mask, d_err=None):
+        """triangulate_dev without any device allocation (fixed scratch, n <= 2^20)."""
+        K, prev_pose, curr_pose, R, t = self._mats(K, prev_pose, curr_pose, R, t)
+        self.check(lib().sfm_triangulate_noalloc_dev(
             self._h, _ptr(K), _ptr(prev_pose), _ptr(curr_pose), _ptr(R), _ptr(t),
             _ptr(d_prev_pts), _ptr(d_curr_pts), C.c_int(n), _ptr(d_bgr), C.c_int(img_w),
             C.c_int(img_h), C.c_size_t(img_stride), C.c_float(min_dist), C.c_float(max_dist),

@@ -145,6 +145,7 @@ static int create_common(int device, hipStream_t stream, bool own, sfm_ctx** out
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->num_cus = prop.multiProcessorCount;
+    sfm::triangulate_scratch_setup(device);
     *out = ctx;
     return SFM_OK;
 }

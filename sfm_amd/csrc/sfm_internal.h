@@ -125,6 +125,10 @@ struct Carver {
     size_t total() const { return align_up(off, 256); }
 };
 
+// Looks up, once per device and with that device current, the address of the fixed scratch
+// array sfm_triangulate_noalloc_dev works in (triangulate_dlt.hip).
+void triangulate_scratch_setup(int device);
+
 // ---- matching (hamming_knn2.hip, l2_knn2_mfma.hip, ratio_cross.hip) --------
 
 // Geometry of one batched 2-NN launch.  A "problem" is one (query frame, train

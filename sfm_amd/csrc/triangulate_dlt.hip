@@ -24,6 +24,7 @@
 // well-conditioned points, against a stated tolerance of 1e-4).
 #include <cfloat>
 #include <cstdlib>
+#include <mutex>
 
 #include "sfm_internal.h"
 
@@ -954,6 +955,59 @@ int sfm_triangulate_matches_dev(sfm_ctx* ctx, const double* K, const double* pre
 
 namespace {
 
+// Scratch of the entry point that allocates nothing (sfm_triangulate_noalloc_dev): the bin
+// counters followed by the deferred-point lists, sized for kNoAllocMaxPoints correspondences.
+// Every GPU the library runs on holds its own copy of this array at its own address until the
+// process ends; host code reaches it only through the per-device pointer below, never by name.
+constexpr int kNoAllocMaxPoints = 1 << 20;
+constexpr int kNoAllocMaxBlocks = kNoAllocMaxPoints / 256;
+constexpr int kNoAllocMaxBinCap = (kNoAllocMaxBlocks + kListBins - 1) / kListBins * 256;
+constexpr size_t kNoAllocInts = (size_t)kListBins + (size_t)kListBins * kNoAllocMaxBinCap;
+static __device__ __align__(256) int scratch[kNoAllocInts];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+int* g_scratch_ptr[kMaxDevices];        // device address of `scratch` on device d, once known
+hipError_t g_scratch_rc[kMaxDevices];   // why it is not known (hipSuccess: not asked yet)
+
+// Lists and counters of one launch pair.
+struct TriLists {
+    int* bin_count;
+    int* list;
+    int bins, bin_cap;
+};
+
+int launch_triangulation(sfm_ctx* ctx, TriArgs& a, const TriLists& l, bool timed) {
+    const int blocks = (a.n + 255) / 256;
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(l.bin_count, 0, sizeof(int) * kListBins, ctx->stream));
+    if (timed) {
+        KernelTimer timer(ctx, KID_TRIANGULATE_DLT);
+        hipLaunchKernelGGL(triangulate_invit_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a,
+                           l.bin_count, l.list, l.bin_cap);
+    } else {
+        hipLaunchKernelGGL(triangulate_invit_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a,
+                           l.bin_count, l.list, l.bin_cap);
+    }
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    if (timed) {
+        KernelTimer timer(ctx, KID_TRIANGULATE_LIST);
+        hipLaunchKernelGGL(triangulate_list_kernel, dim3(l.bins), dim3(256), 0, ctx->stream, a,
+                           l.bin_count, l.list, l.bin_cap);
+    } else {
+        hipLaunchKernelGGL(triangulate_list_kernel, dim3(l.bins), dim3(256), 0, ctx->stream, a,
+                           l.bin_count, l.list, l.bin_cap);
+    }
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+// Bins in use and lanes that can land in one bin, for n correspondences.
+void list_geometry(int n, TriLists* l) {
+    const int blocks = (n + 255) / 256;
+    l->bins = blocks < kListBins ? blocks : kListBins;
+    l->bin_cap = ((blocks + kListBins - 1) / kListBins) * 256;
+}
+
 int run_triangulation(sfm_ctx* ctx, TriArgs& a) {
     const int n = a.n;
     static const bool force_jacobi = [] {
@@ -966,34 +1020,99 @@ int run_triangulation(sfm_ctx* ctx, TriArgs& a) {
         SFM_HIP_CHECK(ctx, hipGetLastError());
         return SFM_OK;
     }
-    const int blocks = (n + 255) / 256;
-    const int bins = blocks < kListBins ? blocks : kListBins;
-    const int bin_cap = ((blocks + kListBins - 1) / kListBins) * 256;  // lanes that can land in one bin
+    TriLists l;
+    list_geometry(n, &l);
     Carver sz(nullptr);
     sz.take<int>(kListBins);
-    sz.take<int>((size_t)bins * bin_cap);
+    sz.take<int>((size_t)l.bins * l.bin_cap);
     void* ws;
     SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
     Carver c(ws);
-    int* bin_count = c.take<int>(kListBins);
-    int* list = c.take<int>((size_t)bins * bin_cap);
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(bin_count, 0, sizeof(int) * kListBins, ctx->stream));
-    {
-        KernelTimer timer(ctx, KID_TRIANGULATE_DLT);
-        hipLaunchKernelGGL(triangulate_invit_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a,
-                           bin_count, list, bin_cap);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
-    }
-    {
-        KernelTimer timer(ctx, KID_TRIANGULATE_LIST);
-        hipLaunchKernelGGL(triangulate_list_kernel, dim3(bins), dim3(256), 0, ctx->stream, a,
-                           bin_count, list, bin_cap);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
-    }
-    return SFM_OK;
+    l.bin_count = c.take<int>(kListBins);
+    l.list = c.take<int>((size_t)l.bins * l.bin_cap);
+    return launch_triangulation(ctx, a, l, true);
 }
 
 }  // namespace
+
+namespace sfm {
+
+// Called by sfm_ctx_create* with `device` current: looks up this device's copy of the scratch
+// array once.  A failure is kept and reported by the entry point that needs the array.
+void triangulate_scratch_setup(int device) {
+    if (device < 0 || device >= kMaxDevices) return;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return;
+    int* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e == hipSuccess && ptr) {
+        g_scratch_ptr[device] = ptr;
+        g_scratch_rc[device] = hipSuccess;
+    } else {
+        g_scratch_rc[device] = e == hipSuccess ? hipErrorInvalidSymbol : e;
+    }
+}
+
+}  // namespace sfm
+
+extern "C" {
+
+int sfm_triangulate_noalloc_max_points(void) { return kNoAllocMaxPoints; }
+
+int sfm_triangulate_noalloc_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
+                                const double* curr_pose, const double* R, const double* t,
+                                const float* d_prev_pts, const float* d_curr_pts, int n,
+                                const uint8_t* d_bgr, int img_w, int img_h, size_t img_stride,
+                                float min_dist, float max_dist, float max_proj_err, double* d_X,
+                                uint8_t* d_rgb, uint8_t* d_mask, double* d_err) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (n < 0) return set_error(ctx, SFM_E_INVALID, "negative point count");
+    if (n > kNoAllocMaxPoints)
+        return set_error(ctx, SFM_E_INVALID,
+                         "sfm_triangulate_noalloc_dev: %d correspondences exceed the fixed scratch "
+                         "(at most %d per call; use sfm_triangulate_dev)", n, kNoAllocMaxPoints);
+    if (n == 0) return SFM_OK;
+    if (!K || !prev_pose || !curr_pose || !R || !t || !d_prev_pts || !d_curr_pts || !d_X || !d_mask)
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (d_bgr && (!d_rgb || img_w <= 0 || img_h <= 0 || img_stride < (size_t)img_w * 3))
+        return set_error(ctx, SFM_E_INVALID, "bad colour image description");
+    if (ctx->device < 0 || ctx->device >= kMaxDevices)
+        return set_error(ctx, SFM_E_UNSUPPORTED, "device %d has no scratch slot", ctx->device);
+    int* ptr;
+    hipError_t why;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        ptr = g_scratch_ptr[ctx->device];
+        why = g_scratch_rc[ctx->device];
+    }
+    if (!ptr)
+        return set_error(ctx, SFM_E_HIP, "hipGetSymbolAddress(scratch) failed on device %d: %s",
+                         ctx->device, hipGetErrorString(why));
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    TriArgs a{};
+    set_cameras(a, K, prev_pose, curr_pose, R, t);
+    a.prev_pts = reinterpret_cast<const float2*>(d_prev_pts);
+    a.curr_pts = reinterpret_cast<const float2*>(d_curr_pts);
+    a.n = n;
+    a.bgr = d_bgr;
+    a.img_w = img_w;
+    a.img_h = img_h;
+    a.img_stride = img_stride;
+    a.min_dist = (double)min_dist;
+    a.max_dist = (double)max_dist;
+    a.max_err = (double)max_proj_err;
+    a.X = d_X;
+    a.rgb = d_rgb;
+    a.mask = d_mask;
+    a.err = d_err;
+    TriLists l;
+    list_geometry(n, &l);
+    l.bin_count = ptr;              // cleared by launch_triangulation: the array keeps the
+    l.list = ptr + kListBins;       // last call's contents
+    return launch_triangulation(ctx, a, l, false);
+}
+
+}  // extern "C"
 
 extern "C" {
 
