@@ -4,8 +4,11 @@ matching as separate workloads).
 
   python bench.py --gpus N --steps K --warmup W [--workload framepair|c3|c4|c5]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL).  Rank 0
-prints ONE JSON line.  The default workload is the one BASELINE.json's metric is
+N > 1 runs one rank per GPU over RCCL: either the caller launches this file under
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or, when
+those are absent, this process starts `python -m torch.distributed.run` itself as a
+child -- before anything here touches the GPU -- waits for it and forwards rank 0's
+line.  Rank 0 prints ONE JSON line.  The default workload is the one BASELINE.json's metric is
 quoted on: per step every rank processes PAIRS frame pairs, each = robust
 matching of two 8192-keypoint ORB frames (2-NN both ways, ratio test,
 cross-check) + pyramidal LK of 5000 points on a 1280x720 pair (21x21 window,
@@ -82,7 +85,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="framepair", choices=["framepair", "c3", "c4", "c5", "f1", "f2", "f3", "vo"])
+    ap.add_argument("--workload", default="framepair", choices=["framepair", "c3", "c4", "c5", "f1", "f2", "f3", "vo", "ranks"],
+                    help="'ranks' only reports the ranks a multi-process launch created (gloo, no GPU)")
     ap.add_argument("--pairs", type=int, default=None,
                     help="frame pairs (problems, frames) per rank and step; default 64 for the "
                          "frame-pair workload, 32 for f1 / f2 / f3 / vo")
@@ -93,7 +97,7 @@ def parse():
                          "(+4 %% throughput; per-kernel event times then include the overlap, so "
                          "the default keeps one stream and clean kernel timings)")
     ap.add_argument("--force-gather", action="store_true",
-                    help="framepair with one rank: run the RCCL all-gather of the match lists anyway "
+                    help="framepair / c5 with one rank: run the RCCL all-gather of the match lists anyway "
                          "(a one-rank process group), to exercise that path on a single GPU")
     return ap.parse_args()
 
@@ -522,12 +526,12 @@ def run_c5(args, rank, world, local):
     pairs = allpairs.window_pairs(F)
     matcher = allpairs.HipPairMatcher(ctx, capi.NORM_HAMMING, d_desc, KPS, DESC_BYTES, 0.5)
     n_local = len(allpairs.shard_indices(len(pairs), rank, world))
-    ctx.reserve(capi.Context.match_pairs_workspace(0, F, KPS, DESC_BYTES, n_local))
+    ctx.reserve(capi.Context.match_pairs_compact_workspace(0, F, KPS, DESC_BYTES, n_local))
     result = {}
 
     def step():
-        c, off, m = allpairs.match_all_pairs(pairs, matcher, rank, world)
-        result["n"] = int(off[-1])
+        c, off, m = allpairs.match_all_pairs(pairs, matcher, rank, world, always_exchange=args.force_gather)
+        result["n"], result["sum_counts"], result["bytes"] = int(off[-1]), int(c.sum()), m.numel() * m.element_size()
 
     dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, ctx)
     roof = hamming_roofline(prof, 2 * n_local, KPS, DESC_BYTES, f"2 dirs x {n_local} pairs")
@@ -553,7 +557,9 @@ def run_c5(args, rank, world, local):
         "ms_per_frame_pair": round(1e3 * dt / args.steps / len(pairs), 5),
         "roofline": roof,
         "kernels": {k: kernel_line(prof, k) for k in sorted(prof)},
-        "check": {"gathered_matches": result.get("n")},
+        "check": {"gathered_matches": result.get("n"), "sum_of_pair_counts": result.get("sum_counts"),
+                  "gathered_bytes": result.get("bytes"),
+                  "record": "6 B (u16 prev row, u16 curr row, u16 Hamming distance)"},
     }
     ctx.close()
     return out
@@ -951,8 +957,64 @@ def run_vo(args, rank, world, local):
     return out
 
 
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N ranks as a child `torch.distributed.run` (fresh
+    processes; this parent never initialises the GPU and is not replaced), forward the one JSON
+    line rank 0 prints and return the child's exit status."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:   # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out.rstrip("\n")
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0:
+        print(f"bench.py: the {args.gpus}-rank launch failed with exit status {rc}", file=sys.stderr)
+        return rc
+    if line is None:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    print(line)
+    return 0
+
+
+def run_ranks():
+    """Launch check without a GPU: every rank reports its RANK / LOCAL_RANK over gloo."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        mine = torch.tensor([rank, local, os.getpid()], dtype=torch.int64)
+        every = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(every, mine)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        every = [torch.tensor([rank, local, os.getpid()])]
+    if rank == 0:
+        print(json.dumps({"metric": "ranks launched", "value": world, "unit": "ranks", "n_gpus": world,
+                          "ranks": [int(e[0]) for e in every], "local_ranks": [int(e[1]) for e in every],
+                          "distinct_processes": len({int(e[2]) for e in every})}))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.workload == "ranks":
+        return run_ranks()
     rank, world, local = dist_setup(args.gpus, args.force_gather)
     run = {"framepair": run_framepair, "c3": run_c3, "c4": run_c4, "c5": run_c5, "f1": run_f1, "f2": run_f2, "f3": run_f3, "vo": run_vo}[args.workload]
     out = run(args, rank, world, local)

@@ -56,6 +56,14 @@ typedef struct sfm_dmatch {
     float distance;
 } sfm_dmatch;
 
+/* Compact match record of the exchange between GPUs (Hamming matching of frames with at most
+ * 65536 rows): prev row, curr row, Hamming distance.  6 bytes. */
+typedef struct sfm_match16 {
+    uint16_t queryIdx;
+    uint16_t trainIdx;
+    uint16_t distance;
+} sfm_match16;
+
 typedef struct sfm_ctx sfm_ctx;
 
 /* ---- context ------------------------------------------------------------ */
@@ -134,6 +142,30 @@ int sfm_match_pairs_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames
                         sfm_dmatch* d_matches, int cap, int32_t* d_match_counts);
 /* Workspace bytes sfm_match_pairs_dev needs for these sizes (sfm_ctx_reserve). */
 size_t sfm_match_pairs_workspace(int norm, int n_frames, int rows_per_frame, int d, int n_pairs);
+
+/* sfm_match_pairs_dev for windowed / all-pairs matching sharded over GPUs (the reference
+ * re-matches the current frame against a window of earlier views, Source Files/
+ * tracking.cpp:127-135, one findRobustMatches per pair): SFM_NORM_HAMMING only, rows_per_frame
+ * <= 65536.  Instead of `cap` cv::DMatch slots per pair the cross-checked matches of all pairs
+ * are written back to back, in pair order and within a pair in findRobustMatches' order, as
+ * sfm_match16 records: pair p occupies d_out[d_offsets[p] .. d_offsets[p+1]); d_offsets has
+ * n_pairs + 1 int64 entries (the last is the total), d_pair_counts n_pairs int32 entries.
+ * Records at or beyond out_cap are not written (the offsets still tell the true total, so the
+ * caller can detect the overflow and repeat with a larger buffer).  Pairs are processed 1024 at
+ * a time through the context's workspace. */
+int sfm_match_pairs_compact_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames,
+                                size_t frame_stride, int rows_per_frame, const int32_t* d_counts,
+                                int d, const int32_t* d_pairs, int n_pairs, float ratio,
+                                sfm_match16* d_out, size_t out_cap, int32_t* d_pair_counts,
+                                int64_t* d_offsets);
+size_t sfm_match_pairs_compact_workspace(int norm, int n_frames, int rows_per_frame, int d, int n_pairs);
+
+/* Reassembly of gathered match lists (no counterpart in the reference, which is one process):
+ * segment s = d_len[s] elements of elem_bytes bytes (even) copied from d_src + d_src_off[s]
+ * elements to d_dst + d_dst_off[s] elements.  Segments must not overlap in d_dst. */
+int sfm_gather_segments_dev(sfm_ctx* ctx, const void* d_src, const int64_t* d_src_off,
+                            const int64_t* d_dst_off, const int32_t* d_len, int n_segments,
+                            int elem_bytes, void* d_dst);
 
 /* ---- pyramidal Lucas-Kanade --------------------------------------------- */
 

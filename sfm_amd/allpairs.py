@@ -27,38 +27,78 @@ def shard_indices(n_pairs, rank, world):
     return np.arange(rank, n_pairs, world, dtype=np.int64)
 
 
-class HipPairMatcher:
-    """match_fn for `match_all_pairs`: the HIP library on this rank's GPU."""
+MATCH16_DTYPE = np.dtype([("queryIdx", "<u2"), ("trainIdx", "<u2"), ("distance", "<u2")])
 
-    def __init__(self, ctx, norm, d_desc, rows_per_frame, d, ratio, d_counts=None):
+
+class HipPairMatcher:
+    """match_fn for `match_all_pairs`: the HIP library on this rank's GPU.
+
+    Matches come back in the library's compact exchange format (sfm_match16: prev row, curr
+    row, Hamming distance as three uint16, held here as an int16 tensor [n, 3]) written back to
+    back in pair order by sfm_match_pairs_compact_dev; the rank never holds a [pairs, rows]
+    cv::DMatch buffer.  The context must enqueue on torch's current stream (the tensors this
+    class hands out are consumed by torch and by the collectives on that stream).
+    """
+
+    def __init__(self, ctx, norm, d_desc, rows_per_frame, d, ratio, d_counts=None, matches_per_pair=None):
+        if ctx.stream is None or ctx.stream != torch.cuda.current_stream(d_desc.device).cuda_stream:
+            raise ValueError("HipPairMatcher needs a Context created on torch's current stream "
+                             "(capi.Context(dev, stream=torch.cuda.current_stream().cuda_stream))")
         self.ctx, self.norm, self.d_desc = ctx, norm, d_desc
         self.rows, self.d, self.ratio, self.d_counts = rows_per_frame, d, float(ratio), d_counts
         self.n_frames = d_desc.shape[0]
         self.frame_stride = d_desc.stride(0) * d_desc.element_size()
-        self._buf = None
+        # first guess of the output size; grown (and the call repeated) when a window needs more
+        self.per_pair = int(matches_per_pair) if matches_per_pair else max(rows_per_frame // 4, 16)
+        self._out = self._counts = self._offsets = self._pairs = None
+
+    def _buffers(self, P, records):
+        dev = self.d_desc.device
+        if self._out is None or self._out.shape[0] < records:
+            self._out = torch.empty((records, 3), dtype=torch.int16, device=dev)
+        if self._counts is None or self._counts.shape[0] < P:
+            self._counts = torch.empty(P, dtype=torch.int32, device=dev)
+            self._offsets = torch.empty(P + 1, dtype=torch.int64, device=dev)
+            self._pairs = torch.empty((P, 2), dtype=torch.int32, device=dev)
 
     def __call__(self, pairs_np):
-        """Returns (counts [P] int32 tensor, matches [sum, 3] int32 tensor: q, t, distance bits)."""
+        """Returns (counts [P] int32 tensor, matches [sum(counts), 3] int16 tensor holding
+        uint16 (q, t, distance) records)."""
         dev = self.d_desc.device
         P = len(pairs_np)
-        cap = self.rows
-        if self._buf is None or self._buf[0].shape[0] < P:
-            self._buf = (torch.empty((P, cap, 4), dtype=torch.int32, device=dev),
-                         torch.empty(P, dtype=torch.int32, device=dev))
-        d_m, d_c = self._buf[0][:P], self._buf[1][:P]
         if P == 0:
-            return d_c, torch.empty((0, 3), dtype=torch.int32, device=dev)
-        d_pairs = torch.from_numpy(np.ascontiguousarray(pairs_np, dtype=np.int32)).to(dev)
-        self.ctx.match_pairs_dev(self.norm, self.d_desc, self.n_frames, self.frame_stride, self.rows,
-                                 self.d_counts, self.d, d_pairs, P, self.ratio, d_m, cap, d_c)
-        return d_c, compact_matches(d_m, d_c)
+            return (torch.empty(0, dtype=torch.int32, device=dev),
+                    torch.empty((0, 3), dtype=torch.int16, device=dev))
+        self._buffers(P, max(P * self.per_pair, 1024))
+        self._pairs[:P].copy_(torch.from_numpy(np.ascontiguousarray(pairs_np, dtype=np.int32)))
+        while True:
+            self.ctx.match_pairs_compact_dev(self.norm, self.d_desc, self.n_frames, self.frame_stride,
+                                             self.rows, self.d_counts, self.d, self._pairs, P, self.ratio,
+                                             self._out, self._out.shape[0], self._counts, self._offsets)
+            total = int(self._offsets[P].item())       # one host read per window
+            if total <= self._out.shape[0]:
+                return self._counts[:P], self._out[:total]
+            self.per_pair = total // P + 1              # overflow: grow and repeat
+            self._buffers(P, int(total * 1.05) + 1024)
+
+    def gather_segments(self, src, src_off, dst_off, lens, total):
+        """dst[dst_off[s] : dst_off[s] + lens[s]] = src[src_off[s] : ...] on the device."""
+        dev = src.device
+        dst = torch.empty((total, src.shape[1]), dtype=src.dtype, device=dev)
+        if total:
+            t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+            self.ctx.gather_segments_dev(src, t(src_off, torch.int64), t(dst_off, torch.int64),
+                                         t(lens, torch.int32), len(lens), src.shape[1] * src.element_size(),
+                                         dst)
+        return dst
 
 
-def compact_matches(d_matches, d_counts):
-    """[P, cap, 4] int32 (cv::DMatch layout) + counts -> [sum(counts), 3] (q, t, distance bits)."""
-    P, cap, _ = d_matches.shape
-    keep = torch.arange(cap, device=d_matches.device)[None, :] < d_counts[:, None]
-    return d_matches[keep][:, [0, 1, 3]].contiguous()
+def gather_segments_host(src, src_off, dst_off, lens, total):
+    """CPU tensors: the same reassembly with an index built on the host."""
+    if total == 0:
+        return src[:0].clone()
+    idx = np.repeat(np.asarray(src_off) - np.asarray(dst_off), lens) + np.arange(total)
+    return src[torch.from_numpy(idx)]
 
 
 class PaddedGather:
@@ -92,20 +132,46 @@ class PaddedGather:
         self._work = ()
 
 
-def match_all_pairs(pairs, match_fn, rank=0, world=1, group=None):
+def reassemble(all_c, all_p, width, n_pairs, world, gather):
+    """Pair order out of the gathered per-rank results.
+
+    all_c: [world, per_rank] int64 numpy, rank r's per-pair counts (-1 pads); all_p: the ranks'
+    payloads one after another, each `width` records long; pair i lives on rank i % world at slot
+    i // world.  Returns (counts [P], offsets [P+1], matches [total, k])."""
+    valid = np.where(all_c > 0, all_c, 0)
+    i = np.arange(n_pairs)
+    r_of, s_of = i % world, i // world
+    counts_out = all_c[r_of, s_of]
+    offsets = np.concatenate([[0], np.cumsum(counts_out)])
+    total = int(offsets[-1])
+    slot_off = np.concatenate([np.zeros((world, 1), np.int64), np.cumsum(valid, axis=1)], axis=1)
+    src_start = r_of * width + slot_off[r_of, s_of]
+    matches = gather(all_p, src_start.astype(np.int64), offsets[:-1].astype(np.int64),
+                     counts_out.astype(np.int32), total)
+    return counts_out, offsets, matches
+
+
+def match_all_pairs(pairs, match_fn, rank=0, world=1, group=None, always_exchange=False):
     """Runs match_fn on this rank's share of `pairs` and gathers every rank's result.
 
-    match_fn(pairs_subset) -> (counts [p] int32, matches [sum(counts), 3] int32) on the
-    device the process group works on.  Returns (counts [P] int64 numpy, offsets [P+1]
-    int64 numpy, matches [total, 3] int32 tensor): pair k's matches are
-    matches[offsets[k]:offsets[k+1]], in the order the matcher produced them.
+    match_fn(pairs_subset) -> (counts [p] int32, matches [sum(counts), k]) on the device the
+    process group works on (k columns of any one dtype: three int16 holding the library's
+    uint16 records for HipPairMatcher).  Returns (counts [P] int64 numpy, offsets [P+1] int64
+    numpy, matches [total, k] tensor): pair i's matches are matches[offsets[i]:offsets[i+1]],
+    in the order the matcher produced them, whatever the number of ranks.
+
+    Exchange: one all-gather of the per-pair counts (int32, padded to the largest share), one
+    host read of them, one all-gather of the payloads padded to the largest rank total (bytes),
+    then a segment copy into pair order.  With one rank there is nothing to exchange unless
+    always_exchange asks for the collectives anyway (a one-rank group: how a single GPU
+    exercises this path).
     """
     pairs = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
     P = len(pairs)
     mine = shard_indices(P, rank, world)
     counts, payload = match_fn(pairs[mine])
     counts = counts.to(torch.int32)
-    if world == 1:
+    if world == 1 and not always_exchange:
         c = counts.cpu().numpy().astype(np.int64)
         off = np.concatenate([[0], np.cumsum(c)])
         return c, off, payload
@@ -115,29 +181,17 @@ def match_all_pairs(pairs, match_fn, rank=0, world=1, group=None):
     # 1. counts: every rank sends per_rank entries (-1 pads the short ranks)
     send_c = torch.full((per_rank,), -1, dtype=torch.int32, device=dev)
     send_c[: len(mine)] = counts
-    all_c = [torch.empty_like(send_c) for _ in range(world)]
-    dist.all_gather(all_c, send_c, group=group)
-    all_c = torch.stack(all_c).cpu().numpy().astype(np.int64)  # [world, per_rank]
+    all_c = torch.empty((world, per_rank), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(all_c.view(-1), send_c, group=group)
+    all_c = all_c.cpu().numpy().astype(np.int64)  # [world, per_rank]
     totals = np.where(all_c > 0, all_c, 0).sum(axis=1)
-    # 2. payload, padded to the largest rank total
-    width = int(totals.max()) if totals.size else 0
-    send_p = torch.zeros((max(width, 1), 3), dtype=torch.int32, device=dev)
+    # 2. payload as bytes, padded to the largest rank total
+    width = max(int(totals.max()) if totals.size else 0, 1)
+    k = payload.shape[1]
+    send_p = torch.zeros((width, k), dtype=payload.dtype, device=dev)
     send_p[: payload.shape[0]] = payload
-    all_p = [torch.empty_like(send_p) for _ in range(world)]
-    dist.all_gather(all_p, send_p, group=group)
-    # 3. reassemble in pair order: pair k lives on rank k % world at slot k // world
-    k = np.arange(P)
-    r_of, s_of = k % world, k // world
-    counts_out = all_c[r_of, s_of]
-    offsets = np.concatenate([[0], np.cumsum(counts_out)])
-    total = int(offsets[-1])
-    if total == 0:
-        return counts_out, offsets, torch.empty((0, 3), dtype=torch.int32, device=dev)
-    valid = np.where(all_c > 0, all_c, 0)
-    rank_base = np.concatenate([[0], np.cumsum(totals)])[:world]          # start of rank r in `cat`
-    slot_off = np.concatenate([np.zeros((world, 1), np.int64), np.cumsum(valid, axis=1)], axis=1)
-    src_start = rank_base[r_of] + slot_off[r_of, s_of]
-    gather = np.repeat(src_start - offsets[:-1], counts_out) + np.arange(total)
-    cat = torch.cat([all_p[r][: int(totals[r])] for r in range(world)])
-    matches = cat[torch.from_numpy(gather).to(dev)]
-    return counts_out, offsets, matches
+    all_p = torch.empty((world * width, k), dtype=payload.dtype, device=dev)
+    dist.all_gather_into_tensor(all_p.view(torch.uint8).view(-1), send_p.view(torch.uint8).view(-1), group=group)
+    # 3. pair order
+    gather = getattr(match_fn, "gather_segments", None) if dev.type != "cpu" else None
+    return reassemble(all_c, all_p, width, P, world, gather or gather_segments_host)

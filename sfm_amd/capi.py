@@ -33,6 +33,7 @@ EXPORTS = [
     "sfm_ctx_profile_read",
     "sfm_knn2", "sfm_knn2_dev", "sfm_ratio_matches", "sfm_robust_matches",
     "sfm_match_pairs_dev", "sfm_match_pairs_workspace",
+    "sfm_match_pairs_compact_dev", "sfm_match_pairs_compact_workspace", "sfm_gather_segments_dev",
     "sfm_pyrlk", "sfm_pyrlk_batch_dev", "sfm_pyrlk_workspace",
     "sfm_triangulate", "sfm_triangulate_dev", "sfm_triangulate_matches_dev",
     "sfm_triangulate_noalloc_dev", "sfm_triangulate_noalloc_max_points",
@@ -70,7 +71,7 @@ def lib():
         l.sfm_profile_kernel_name.restype = C.c_char_p
         l.sfm_ctx_destroy.restype = None
         l.sfm_ctx_destroy.argtypes = [C.c_void_p]
-        for name in ("sfm_match_pairs_workspace", "sfm_pyrlk_workspace", "sfm_fundamental_workspace",
+        for name in ("sfm_match_pairs_workspace", "sfm_match_pairs_compact_workspace", "sfm_pyrlk_workspace", "sfm_fundamental_workspace",
                      "sfm_epipolar_filter_pairs_workspace", "sfm_good_features_workspace", "sfm_good_features_batch_workspace", "sfm_find_essential_workspace", "sfm_recover_pose_workspace",
                      "sfm_find_camera_pose_workspace"):
             if hasattr(l, name):
@@ -104,6 +105,7 @@ class Context:
         if rc != 0:
             raise SfmError(l.sfm_last_error(None).decode())
         self.device = device
+        self.stream = None if stream is None else int(stream)   # None: a stream of the context's own
 
     def close(self):
         if self._h:
@@ -204,6 +206,25 @@ class Context:
             self._h, C.c_int(norm), _ptr(d_desc), C.c_int(n_frames), C.c_size_t(frame_stride),
             C.c_int(rows_per_frame), _ptr(d_counts), C.c_int(d), _ptr(d_pairs), C.c_int(n_pairs),
             C.c_float(ratio), _ptr(d_matches), C.c_int(cap), _ptr(d_match_counts)))
+
+    def match_pairs_compact_dev(self, norm, d_desc, n_frames, frame_stride, rows_per_frame, d_counts, d,
+                                d_pairs, n_pairs, ratio, d_out, out_cap, d_pair_counts, d_offsets):
+        """All pairs' cross-checked matches back to back as 6-byte (q, t, distance) records."""
+        self.check(lib().sfm_match_pairs_compact_dev(
+            self._h, C.c_int(norm), _ptr(d_desc), C.c_int(n_frames), C.c_size_t(frame_stride),
+            C.c_int(rows_per_frame), _ptr(d_counts), C.c_int(d), _ptr(d_pairs), C.c_int(n_pairs),
+            C.c_float(ratio), _ptr(d_out), C.c_size_t(out_cap), _ptr(d_pair_counts), _ptr(d_offsets)))
+
+    @staticmethod
+    def match_pairs_compact_workspace(norm, n_frames, rows_per_frame, d, n_pairs):
+        return int(lib().sfm_match_pairs_compact_workspace(C.c_int(norm), C.c_int(n_frames),
+                                                           C.c_int(rows_per_frame), C.c_int(d),
+                                                           C.c_int(n_pairs)))
+
+    def gather_segments_dev(self, d_src, d_src_off, d_dst_off, d_len, n_segments, elem_bytes, d_dst):
+        self.check(lib().sfm_gather_segments_dev(self._h, _ptr(d_src), _ptr(d_src_off), _ptr(d_dst_off),
+                                                 _ptr(d_len), C.c_int(n_segments), C.c_int(elem_bytes),
+                                                 _ptr(d_dst)))
 
     @staticmethod
     def match_pairs_workspace(norm, n_frames, rows_per_frame, d, n_pairs):

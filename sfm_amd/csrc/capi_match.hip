@@ -316,9 +316,15 @@ int sfm_match_pairs_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames
     if (n_pairs < 0 || n_frames < 0 || cap < 0)
         return set_error(ctx, SFM_E_INVALID, "negative count");
     if (n_pairs == 0) return SFM_OK;
-    if (!d_desc || !d_pairs || !d_matches || !d_match_counts)
+    if (!d_match_counts || ((rows_per_frame > 0 && cap > 0) && (!d_desc || !d_pairs || !d_matches)))
         return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
     SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (rows_per_frame < 2) {  // no ratio test can pass: every pair has no match
+        SFM_HIP_CHECK(ctx, hipMemsetAsync(d_match_counts, 0, sizeof(int32_t) * (size_t)n_pairs, ctx->stream));
+        return SFM_OK;
+    }
+    if (!d_desc || !d_pairs || (cap > 0 && !d_matches))
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
     if (norm != SFM_NORM_HAMMING)
         return l2_match_frames_dev(ctx, norm == SFM_NORM_L2SQR, static_cast<const float*>(d_desc),
                                    n_frames, frame_stride, rows_per_frame, d_counts, d, d_pairs,
@@ -367,6 +373,101 @@ int sfm_match_pairs_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames
                                            c));
     }
     return SFM_OK;
+}
+
+size_t sfm_match_pairs_compact_workspace(int norm, int n_frames, int rows_per_frame, int d, int n_pairs) {
+    if (norm != SFM_NORM_HAMMING || n_frames <= 0 || rows_per_frame <= 0 || d <= 0 || n_pairs <= 0) return 0;
+    const int chunk = std::min(n_pairs, kPairChunk);
+    Carver c(nullptr);
+    c.take<sfm_dmatch>((size_t)chunk * rows_per_frame);
+    return c.total() + align_up(sfm_match_pairs_workspace(norm, n_frames, rows_per_frame, d, n_pairs), 256);
+}
+
+int sfm_match_pairs_compact_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames,
+                                size_t frame_stride, int rows_per_frame, const int32_t* d_counts, int d,
+                                const int32_t* d_pairs, int n_pairs, float ratio, sfm_match16* d_out,
+                                size_t out_cap, int32_t* d_pair_counts, int64_t* d_offsets) {
+    SFM_RETURN_IF(check_common(ctx, norm, rows_per_frame, rows_per_frame, d));
+    if (norm != SFM_NORM_HAMMING)
+        return set_error(ctx, SFM_E_UNSUPPORTED, "compact match records hold Hamming distances only");
+    if (rows_per_frame > 65536)
+        return set_error(ctx, SFM_E_UNSUPPORTED, "compact match records index at most 65536 rows per frame");
+    if (n_pairs < 0 || n_frames < 0) return set_error(ctx, SFM_E_INVALID, "negative count");
+    if (!d_offsets) return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (n_pairs == 0 || rows_per_frame < 2) {
+        SFM_HIP_CHECK(ctx, hipMemsetAsync(d_offsets, 0, sizeof(int64_t) * ((size_t)n_pairs + 1), ctx->stream));
+        if (n_pairs > 0) {
+            if (!d_pair_counts) return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+            SFM_HIP_CHECK(ctx, hipMemsetAsync(d_pair_counts, 0, sizeof(int32_t) * (size_t)n_pairs, ctx->stream));
+        }
+        return SFM_OK;
+    }
+    if (!d_desc || !d_pairs || !d_pair_counts || (out_cap > 0 && !d_out))
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (frame_stride < (size_t)rows_per_frame * d)
+        return set_error(ctx, SFM_E_INVALID, "frame stride smaller than a frame");
+
+    const int chunk = std::min(n_pairs, kPairChunk);
+    const int cap = rows_per_frame;
+    KnnPlan plan = make_knn_plan(ctx, norm, d, rows_per_frame, rows_per_frame, 2 * chunk);
+    const size_t row_bytes = (size_t)plan.row_words * 4;
+    const bool packed = d == plan.row_words * 4 && (frame_stride & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(d_desc) & 15) == 0;
+    const HammingPath path = hamming_path(ctx, plan.row_words, plan.rows_max, chunk);
+    const size_t expanded_bytes =
+        path == kPathMfma ? (size_t)n_frames * hamming_mfma_frame_bytes(plan.row_words, rows_per_frame) : 0;
+    Carver sz(nullptr);
+    sz.take<sfm_dmatch>((size_t)chunk * cap);
+    if (!packed) sz.take<uint8_t>((size_t)n_frames * rows_per_frame * row_bytes);
+    if (expanded_bytes) sz.take<uint8_t>(expanded_bytes);
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, sz.total() + hamming_pairs_bytes(ctx, plan, path, chunk), &ws));
+    Carver c(ws);
+    sfm_dmatch* chunk_matches = c.take<sfm_dmatch>((size_t)chunk * cap);
+    const void* base = d_desc;
+    size_t fstride = frame_stride;
+    if (!packed) {
+        uint8_t* p = c.take<uint8_t>((size_t)n_frames * rows_per_frame * row_bytes);
+        fstride = (size_t)rows_per_frame * row_bytes;
+        for (int f = 0; f < n_frames; ++f)
+            SFM_RETURN_IF(pack_rows(ctx, static_cast<const uint8_t*>(d_desc) + f * frame_stride,
+                                    rows_per_frame, (size_t)d, d, p + f * fstride, plan.row_words));
+        base = p;
+    }
+    void* expanded = nullptr;
+    if (expanded_bytes) {
+        expanded = c.take<uint8_t>(expanded_bytes);
+        SFM_RETURN_IF(launch_hamming_expand(ctx, base, fstride, plan.row_words, rows_per_frame, n_frames,
+                                            expanded));
+    }
+    const size_t carve_mark = c.off;
+    for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
+        const int np = std::min(chunk, n_pairs - p0);
+        c.off = carve_mark;
+        SFM_RETURN_IF(hamming_pairs_packed(ctx, plan, path, base, fstride, expanded, rows_per_frame, d_counts,
+                                           d_pairs + 2 * (size_t)p0, np, ratio, chunk_matches, cap,
+                                           d_pair_counts + p0, c));
+        SFM_RETURN_IF(launch_compact_matches(ctx, chunk_matches, d_pair_counts + p0, np, cap, p0 == 0,
+                                             reinterpret_cast<long long*>(d_offsets) + p0, d_out,
+                                             (long long)out_cap));
+    }
+    return SFM_OK;
+}
+
+int sfm_gather_segments_dev(sfm_ctx* ctx, const void* d_src, const int64_t* d_src_off,
+                            const int64_t* d_dst_off, const int32_t* d_len, int n_segments, int elem_bytes,
+                            void* d_dst) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (n_segments < 0 || elem_bytes <= 0 || (elem_bytes & 1))
+        return set_error(ctx, SFM_E_INVALID, "segment count must be >= 0 and the element size even");
+    if (n_segments == 0) return SFM_OK;
+    if (!d_src || !d_src_off || !d_dst_off || !d_len || !d_dst)
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return launch_gather_segments(ctx, d_src, reinterpret_cast<const long long*>(d_src_off),
+                                  reinterpret_cast<const long long*>(d_dst_off), d_len, n_segments,
+                                  elem_bytes / 2, d_dst);
 }
 
 int sfm_robust_matches(sfm_ctx* ctx, int norm, const void* prev, int n_prev, size_t prev_stride,

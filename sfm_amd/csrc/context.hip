@@ -214,7 +214,7 @@ const char* sfm_profile_kernel_name(int kernel_id) {
         "triangulate_dlt_kernel", "triangulate_list_kernel", "fm_subsets_kernel", "fm_solve_kernel",
         "fm_score_kernel", "fm_select_kernel", "corner_eig_kernel", "corner_pick_kernel",
         "corner_sort", "corner_select_kernel", "em_advance_kernel", "em_solve_kernel", "em_score_kernel",
-        "pose_kernels", "hamming_mfma_kernel", "hamming_expand_kernel"};
+        "pose_kernels", "hamming_mfma_kernel", "hamming_expand_kernel", "compact_matches_kernels"};
     return kernel_id >= 0 && kernel_id < sfm::KID_COUNT ? names[kernel_id] : "";
 }
 

@@ -269,6 +269,7 @@ KnnPlan make_knn_plan(const sfm_ctx* ctx, int norm, int d, int nq_max, int nt_ma
     }();
     const long want = (long)per_cu * ctx->num_cus;
     long blocks = (long)qtiles * n_problems;
+    if (blocks < 1) blocks = 1;  // an empty query set or no problems: any plan will do
     int splits = (int)((want + blocks - 1) / blocks);
     // at least 64 train rows per split
     (void)tile_rows;

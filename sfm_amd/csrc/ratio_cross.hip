@@ -314,6 +314,102 @@ int launch_ratio_cross_knn(sfm_ctx* ctx, const int32_t* d_knn_idx, const float* 
     return SFM_OK;
 }
 
+namespace {
+
+// Offsets of one chunk of pairs in the compact output: exclusive scan of min(count, cap) over
+// the chunk's n pairs, continuing from offsets[0] (which the first chunk sets to 0).  One
+// workgroup; a chunk holds at most kThreads pairs.
+__global__ __launch_bounds__(kThreads) void compact_offsets_kernel(const int32_t* __restrict__ counts, int n,
+                                                                   int cap, int first_chunk,
+                                                                   long long* __restrict__ offsets) {
+    __shared__ long long wave_sum[kThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int c = tid < n ? counts[tid] : 0;
+    c = c < 0 ? 0 : (c > cap ? cap : c);
+    // inclusive scan within the wave
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    long long base = first_chunk ? 0 : offsets[0];
+    for (int w = 0; w < wave; ++w) base += wave_sum[w];
+    __syncthreads();
+    if (tid == 0 && first_chunk) offsets[0] = 0;
+    if (tid < n) offsets[tid + 1] = base + incl;
+}
+
+// Pair p's first min(count, cap) matches as 6-byte records at out + offsets[p]; records that
+// would land at or beyond out_cap are dropped.  grid = (pairs of the chunk, slices of a pair).
+__global__ __launch_bounds__(256) void compact_write_kernel(const sfm_dmatch* __restrict__ matches,
+                                                            const int32_t* __restrict__ counts, int cap,
+                                                            const long long* __restrict__ offsets,
+                                                            sfm_match16* __restrict__ out, long long out_cap) {
+    const int pair = blockIdx.x;
+    int c = counts[pair];
+    c = c < 0 ? 0 : (c > cap ? cap : c);
+    const long long base = offsets[pair];
+    const sfm_dmatch* m = matches + (size_t)pair * cap;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < c; i += gridDim.y * blockDim.x) {
+        const long long o = base + i;
+        if (o >= out_cap) break;
+        sfm_match16 r;
+        r.queryIdx = (uint16_t)m[i].queryIdx;
+        r.trainIdx = (uint16_t)m[i].trainIdx;
+        r.distance = (uint16_t)m[i].distance;
+        out[o] = r;
+    }
+}
+
+// Segment s: len[s] elements of `words` 16-bit words from src + src_off[s] to dst + dst_off[s]
+// (offsets in elements).  One workgroup walks segments blockIdx.x, + gridDim.x, ...
+__global__ __launch_bounds__(256) void gather_segments_kernel(const uint16_t* __restrict__ src,
+                                                              const long long* __restrict__ src_off,
+                                                              const long long* __restrict__ dst_off,
+                                                              const int32_t* __restrict__ len, int n_segments,
+                                                              int words, uint16_t* __restrict__ dst) {
+    for (int s = blockIdx.x; s < n_segments; s += gridDim.x) {
+        const long long n = (long long)(len[s] < 0 ? 0 : len[s]) * words;
+        const uint16_t* a = src + src_off[s] * words;
+        uint16_t* b = dst + dst_off[s] * words;
+        for (long long i = threadIdx.x; i < n; i += blockDim.x) b[i] = a[i];
+    }
+}
+
+}  // namespace
+
+int launch_compact_matches(sfm_ctx* ctx, const sfm_dmatch* d_matches, const int32_t* d_counts, int n_pairs,
+                           int cap, bool first_chunk, long long* d_offsets, sfm_match16* d_out,
+                           long long out_cap) {
+    if (n_pairs <= 0) return SFM_OK;
+    if (n_pairs > kThreads) return set_error(ctx, SFM_E_INVALID, "compaction chunk above %d pairs", kThreads);
+    KernelTimer timer(ctx, KID_COMPACT_MATCHES);
+    hipLaunchKernelGGL(compact_offsets_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, d_counts, n_pairs, cap,
+                       first_chunk ? 1 : 0, d_offsets);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    const int slices = n_pairs >= 512 ? 1 : (n_pairs >= 64 ? 4 : 16);
+    hipLaunchKernelGGL(compact_write_kernel, dim3(n_pairs, slices), dim3(256), 0, ctx->stream, d_matches,
+                       d_counts, cap, d_offsets, d_out, out_cap);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+int launch_gather_segments(sfm_ctx* ctx, const void* d_src, const long long* d_src_off,
+                           const long long* d_dst_off, const int32_t* d_len, int n_segments, int words,
+                           void* d_dst) {
+    if (n_segments <= 0) return SFM_OK;
+    KernelTimer timer(ctx, KID_COMPACT_MATCHES);
+    const int blocks = n_segments < 65536 ? n_segments : 65536;
+    hipLaunchKernelGGL(gather_segments_kernel, dim3(blocks), dim3(256), 0, ctx->stream,
+                       static_cast<const uint16_t*>(d_src), d_src_off, d_dst_off, d_len, n_segments, words,
+                       static_cast<uint16_t*>(d_dst));
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
 int launch_ratio_compact(sfm_ctx* ctx, const int32_t* d_idx, const float* d_dist, int nq, int nt,
                          float ratio, sfm_dmatch* d_out, int32_t* d_count) {
     KernelTimer timer(ctx, KID_RATIO_COMPACT);

@@ -44,6 +44,7 @@ enum KernelId {
     KID_POSE,
     KID_HAMMING_MFMA,
     KID_HAMMING_EXPAND,
+    KID_COMPACT_MATCHES,
     KID_COUNT
 };
 struct TimedLaunch {
@@ -225,5 +226,15 @@ int launch_ratio_cross(sfm_ctx* ctx, const KnnPlan& plan, const uint32_t* d_keys
                        const int32_t* d_pairs, int n_pairs, float ratio, int32_t* d_best,
                        float* d_best_dist, sfm_dmatch* d_matches, int cap,
                        int32_t* d_match_counts);
+
+// Appends the chunk's match lists (pair p: min(count, cap) entries of d_matches + p * cap) to
+// the compact output as 6-byte records and writes d_offsets[1 .. n_pairs] (d_offsets[0] is the
+// running start: set to 0 when first_chunk, else left by the chunk before).
+int launch_compact_matches(sfm_ctx* ctx, const sfm_dmatch* d_matches, const int32_t* d_counts, int n_pairs,
+                           int cap, bool first_chunk, long long* d_offsets, sfm_match16* d_out,
+                           long long out_cap);
+int launch_gather_segments(sfm_ctx* ctx, const void* d_src, const long long* d_src_off,
+                           const long long* d_dst_off, const int32_t* d_len, int n_segments, int words,
+                           void* d_dst);
 
 }  // namespace sfm

@@ -226,3 +226,31 @@ def test_bench_roofline_entries():
     assert lk["kernel"] == "lk_track_kernel" and abs(lk["achieved"] - macs / 600e-6 / 1e12) < 0.01
     assert lk["iterations_source"].startswith("cpu_baseline")
     assert bench.lk_roofline(prof, 32, None)["iterations_per_point"] == bench.LK_ITERS_PER_POINT
+
+
+def test_bench_gpus_n_starts_n_ranks():
+    """`bench.py --gpus 2` without a launcher starts two ranks of its own (fresh child
+    processes with distinct LOCAL_RANKs) and forwards rank 0's single JSON line."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "ranks"],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == [0, 1] and out["local_ranks"] == [0, 1]
+    assert out["distinct_processes"] == 2
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a machine without a GPU")
+def test_bench_failed_rank_gives_nonzero_exit():
+    """A rank that fails (no GPU here) makes the launching bench.py exit non-zero, with no
+    result line on stdout."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c5",
+                        "--frames", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
