@@ -103,12 +103,21 @@ int sfm_ctx_profile_read(sfm_ctx* ctx, int kernel_id, double* total_ms, int* lau
  * `d` floats and strides are in bytes too.  idx and dist are [nq][2]; equal
  * distances keep the lower train index first; a slot without a neighbour
  * (nt < 2) holds idx -1 and dist FLT_MAX.  nt must be below 2^18 (OpenCV's own
- * limit for one train image). */
+ * limit for one train image).  L2 distances are the sequential float sum
+ * d += (a-b)*(a-b) in element order (square root taken for SFM_NORM_L2), whatever the
+ * inputs: the matrix cores only select candidates, and a query whose candidates cannot be
+ * proven to contain the two nearest rows is recomputed against every train row. */
 int sfm_knn2(sfm_ctx* ctx, int norm, const void* q, int nq, size_t q_stride,
              const void* t, int nt, size_t t_stride, int d, int32_t* idx, float* dist);
 int sfm_knn2_dev(sfm_ctx* ctx, int norm, const void* d_q, int nq, size_t q_stride,
                  const void* d_t, int nt, size_t t_stride, int d, int32_t* d_idx,
                  float* d_dist);
+
+/* Measurement aid (no counterpart in the reference): how many queries of the last L2 / L2SQR
+ * call on this context (sfm_knn2*, sfm_ratio_matches, sfm_robust_matches, sfm_match_pairs_dev)
+ * could not be proven exact from the matrix-core candidates and were recomputed against every
+ * train row.  Synchronises the stream. */
+int sfm_l2_exhaustive_count(sfm_ctx* ctx, int* count);
 
 /* DescriptorMatcher::ratioMaches, Source Files/feature_processing.cpp:118-130:
  * 2-NN followed by  k[0].distance < ratio * k[1].distance.  out has room for nq

@@ -31,7 +31,7 @@ EXPORTS = [
     "sfm_ctx_reserve", "sfm_last_error", "sfm_version",
     "sfm_ctx_set_profiling", "sfm_profile_kernel_count", "sfm_profile_kernel_name",
     "sfm_ctx_profile_read",
-    "sfm_knn2", "sfm_knn2_dev", "sfm_ratio_matches", "sfm_robust_matches",
+    "sfm_l2_exhaustive_count", "sfm_knn2", "sfm_knn2_dev", "sfm_ratio_matches", "sfm_robust_matches",
     "sfm_match_pairs_dev", "sfm_match_pairs_workspace",
     "sfm_match_pairs_compact_dev", "sfm_match_pairs_compact_workspace", "sfm_gather_segments_dev",
     "sfm_pyrlk", "sfm_pyrlk_batch_dev", "sfm_pyrlk_workspace",
@@ -167,6 +167,12 @@ class Context:
                                   C.c_size_t(t.strides[0] if nt else d * q.itemsize), C.c_int(d),
                                   _ptr(idx), _ptr(dist)))
         return idx, dist
+
+    def l2_exhaustive_count(self):
+        """Queries of the last L2 call that were recomputed against every train row."""
+        n = C.c_int(0)
+        self.check(lib().sfm_l2_exhaustive_count(self._h, C.byref(n)))
+        return n.value
 
     def knn2_dev(self, norm, d_q, nq, q_stride, d_t, nt, t_stride, d, d_idx, d_dist):
         self.check(lib().sfm_knn2_dev(self._h, C.c_int(norm), _ptr(d_q), C.c_int(nq),

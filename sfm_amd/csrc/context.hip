@@ -146,6 +146,14 @@ static int create_common(int device, hipStream_t stream, bool own, sfm_ctx** out
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->num_cus = prop.multiProcessorCount;
     sfm::triangulate_scratch_setup(device);
+    e = hipMalloc(reinterpret_cast<void**>(&ctx->stats), 256);
+    if (e == hipSuccess) e = hipMemset(ctx->stats, 0, 256);
+    if (e != hipSuccess) {
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return sfm::set_error(nullptr, SFM_E_NOMEM, "hipMalloc of the context's counters failed: %s",
+                              hipGetErrorString(e));
+    }
     *out = ctx;
     return SFM_OK;
 }
@@ -167,6 +175,7 @@ void sfm_ctx_destroy(sfm_ctx* ctx) {
         (void)hipEventDestroy(t.stop);
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->stats) (void)hipFree(ctx->stats);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->staging) (void)hipFree(ctx->staging);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -192,6 +201,15 @@ const char* sfm_last_error(const sfm_ctx* ctx) {
 
 const char* sfm_version(void) { return "sfm_hip 0.1 gfx950"; }
 
+int sfm_l2_exhaustive_count(sfm_ctx* ctx, int* count) {
+    if (!ctx || !count) return sfm::set_error(ctx, SFM_E_INVALID, "NULL argument");
+    int32_t v = 0;
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(&v, ctx->stats, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *count = v;
+    return SFM_OK;
+}
+
 int sfm_ctx_set_profiling(sfm_ctx* ctx, int enabled) {
     if (!ctx) return sfm::set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
     SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -214,7 +232,7 @@ const char* sfm_profile_kernel_name(int kernel_id) {
         "triangulate_dlt_kernel", "triangulate_list_kernel", "fm_subsets_kernel", "fm_solve_kernel",
         "fm_score_kernel", "fm_select_kernel", "corner_eig_kernel", "corner_pick_kernel",
         "corner_sort", "corner_select_kernel", "em_advance_kernel", "em_solve_kernel", "em_score_kernel",
-        "pose_kernels", "hamming_mfma_kernel", "hamming_expand_kernel", "compact_matches_kernels"};
+        "pose_kernels", "hamming_mfma_kernel", "hamming_expand_kernel", "compact_matches_kernels", "l2_exhaustive_kernel"};
     return kernel_id >= 0 && kernel_id < sfm::KID_COUNT ? names[kernel_id] : "";
 }
 

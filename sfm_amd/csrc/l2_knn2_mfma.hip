@@ -22,10 +22,19 @@
 //      keys the squared distance is recomputed as the sequential float sum
 //      d += (a-b)*(a-b)  (the scalar order of OpenCV's normL2Sqr), the square root
 //      is taken for NORM_L2, and the best two are chosen by (distance, train index).
-//      The results therefore do not depend on the rounding of the MFMA form, unless
-//      three or more train rows of one candidate list, or more than six candidates
-//      of a query, lie within fp32 rounding of the second-best distance.
+//      Every train row that was NOT re-scored has a ranking key at least T = the smaller
+//      of the ninth-smallest candidate key and the third-smallest key of any candidate
+//      list (the candidate pass keeps that third key too).  With a bound E on the
+//      difference between a row's sequential distance and its MFMA key + ||q||^2, the
+//      result is proven exact when T + ||q||^2 - E exceeds the re-scored second-best
+//      squared distance; a query for which it does not is appended to a list.
+//   3. Exhaustive pass over the listed queries (normally none): one workgroup per query
+//      recomputes the sequential distance to EVERY train row and takes the best two by
+//      (distance, train index).  Results are therefore always those of the sequential
+//      sum with the lower-index tie-break, whatever the rounding of the MFMA form.
+#include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 
 #include "sfm_internal.h"
 
@@ -59,6 +68,7 @@ struct L2Args {
     int qtiles, splits, blocks_per_group;
     int32_t* cand;  // [problem][split][rows_cap][4]
     float* cand_key;  // the candidates' ranking keys ||t||^2 - 2 q.t, same layout
+    float* cand_third;  // [problem][split][rows_cap][2]: third-smallest key of each candidate list
 };
 
 __device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
@@ -117,11 +127,12 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
             qreg[n][m][3] = -2.f * v.w;
         }
     }
-    float best0[NT], best1[NT];
+    float best0[NT], best1[NT], third[NT];
     int bidx0[NT], bidx1[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         best0[n] = best1[n] = FLT_MAX;
+        third[n] = INFINITY;
         bidx0[n] = bidx1[n] = -1;
     }
 
@@ -177,6 +188,8 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
             const float key = acc[mt][n][4 * gq + r];
             const int ti = tbase + 32 * mt + 8 * gq + 4 * lh + r;
             const bool c0 = key < best0[n], c1 = key < best1[n];
+            // the key that does not stay in the list, max(key, old second), may be the new third
+            third[n] = __builtin_amdgcn_fmed3f(third[n], key, best1[n]);
             const float t = c1 ? key : best1[n];
             const int tix = c1 ? ti : bidx1[n];
             best1[n] = c0 ? best0[n] : t;
@@ -263,6 +276,7 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
             cand[(size_t)qi * 4 + 2 * lh + 1] = bidx1[n];
             ckey[(size_t)qi * 4 + 2 * lh] = best0[n];
             ckey[(size_t)qi * 4 + 2 * lh + 1] = best1[n];
+            a.cand_third[cbase / 2 + (size_t)qi * 2 + lh] = third[n];
         }
     }
 }
@@ -284,6 +298,24 @@ __global__ void l2_pack_kernel(const uint8_t* __restrict__ src, int n, size_t sr
     if (lane == 0) norms[row] = acc;
 }
 
+// Squared distance as the sequential float sum d += (a-b)*(a-b), the scalar order of OpenCV's
+// normL2Sqr.  Rows are zero-padded to K floats and (0 - 0)^2 adds an exact zero, so running
+// to K changes nothing.
+__device__ __forceinline__ float sequential_sqr(const float* qrow, const float* trow, int K) {
+    const floatx4* q4 = reinterpret_cast<const floatx4*>(qrow);
+    const floatx4* t4 = reinterpret_cast<const floatx4*>(trow);
+    float d = 0.f;
+    for (int j = 0; j < K / 4; ++j) {
+        const floatx4 qa = q4[j], ta = t4[j];
+        const float v0 = qa.x - ta.x, v1 = qa.y - ta.y, v2 = qa.z - ta.z, v3 = qa.w - ta.w;
+        d += v0 * v0;
+        d += v1 * v1;
+        d += v2 * v2;
+        d += v3 * v3;
+    }
+    return d;
+}
+
 struct RescoreArgs {
     const float* q_base;
     const float* t_base;
@@ -297,8 +329,15 @@ struct RescoreArgs {
     int squared;
     const int32_t* cand;
     const float* cand_key;
+    const float* cand_third;
+    const float* q_norms;  // ||q||^2 per packed row, rows_cap per frame
+    const float* t_norm_max;  // largest ||t||^2 of any packed row (one float)
+    int force_exhaustive;
     int32_t* knn_idx;  // [problem][rows_cap][2]
     float* knn_dist;
+    int32_t* todo_count;  // queries whose result is not proven: count, then (problem, query) pairs
+    int32_t* todo;
+    int32_t* stat_exhaustive;  // per-context total of such queries since the entry point began
 };
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
@@ -346,6 +385,7 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
         }
     }
     bool chosen = ncand <= kRescored;
+    unsigned long long ninth = ~0ull;  // smallest (key, index) among the candidates not re-scored
     if (!chosen) {
         unsigned long long rest = pre;
 #pragma unroll 1
@@ -357,34 +397,137 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
                 rest = ~0ull;
             }
         }
+        ninth = wave_min_u64(rest);
     }
     if (!chosen) ti = -1;
-    unsigned long long key = ~0ull;
+    // T: no train row outside the re-scored set has a smaller ranking key (orderable form)
+    unsigned long long others = ninth;
+    if (lane < 2 * a.splits) {
+        const int split = lane >> 1, half = lane & 1;
+        const float k3 = a.cand_third[((((size_t)problem * a.splits + split) * a.rows_cap) + q) * 2 + half];
+        const unsigned u = __float_as_uint(k3);
+        const unsigned ord = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+        const unsigned long long v = ((unsigned long long)ord << 32) | 0xFFFFFFFFu;
+        others = v < others ? v : others;
+    }
+    others = wave_min_u64(others);
+    unsigned long long key = ~0ull;   // (distance, train index)
     if (ti >= 0) {
-        // Scalar order of OpenCV's normL2Sqr; rows are zero-padded to K floats and
-        // (0 - 0)^2 adds an exact zero, so running to K changes nothing.
-        const floatx4* q4 = reinterpret_cast<const floatx4*>(qrow);
-        const floatx4* t4 = reinterpret_cast<const floatx4*>(trows + (size_t)ti * a.K);
-        float d = 0.f;
-        for (int j = 0; j < a.K / 4; ++j) {
-            const floatx4 qa = q4[j], ta = t4[j];
-            const float v0 = qa.x - ta.x, v1 = qa.y - ta.y, v2 = qa.z - ta.z, v3 = qa.w - ta.w;
-            d += v0 * v0;
-            d += v1 * v1;
-            d += v2 * v2;
-            d += v3 * v3;
-        }
+        float d = sequential_sqr(qrow, trows + (size_t)ti * a.K, a.K);
         if (!a.squared) d = sqrtf(d);  // batchDistL2_32f
         key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)ti;
     }
     const unsigned long long k0 = wave_min_u64(key);
     const unsigned long long k1 = wave_min_u64(key == k0 ? ~0ull : key);
+    // Proof that no other row can reach the second place: its sequential squared distance is
+    // at least its ranking key + ||q||^2 - E >= T + ||q||^2 - E.  E bounds the rounding of the
+    // norms (pairwise sums), of the K accumulation steps of the matrix pipe (each at most one
+    // rounding of a partial sum <= ||t||^2 + 2 sum |q_j t_j| <= ||q||^2 + 2 ||t||^2) and of the
+    // sequential sum itself (relative (K + 3) eps of a value <= 2 (||q||^2 + ||t||^2)); the
+    // factor below is more than twice their total.
+    bool proven = true;
+    if (others != ~0ull) {   // there are train rows outside the re-scored set
+        if (k1 == ~0ull) {
+            proven = false;
+        } else {
+            const unsigned ord = (unsigned)(others >> 32);
+            const unsigned u = ord ^ ((ord >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+            const double T = (double)__uint_as_float(u);
+            const double qn = (double)a.q_norms[(size_t)qf * a.rows_cap + q];
+            const double E = (4.0 * a.K + 64.0) * (double)FLT_EPSILON * (qn + (double)*a.t_norm_max);
+            // NORM_L2 ranks by the rounded square root, which maps neighbouring sums to one
+            // value: a row ties or wins only if its sum is below the square of the next float
+            const float d1 = __uint_as_float((unsigned)(k1 >> 32));
+            const double d1n = (double)nextafterf(d1, INFINITY);
+            proven = T + qn - E > (a.squared ? (double)d1 : d1n * d1n);
+        }
+    }
+    if (a.force_exhaustive) proven = false;
+    if (lane == 0 && !proven) {
+        const int slot = atomicAdd(a.todo_count, 1);
+        atomicAdd(a.stat_exhaustive, 1);
+        a.todo[2 * (size_t)slot] = problem;
+        a.todo[2 * (size_t)slot + 1] = q;
+    }
     if (lane == 0) {
         const size_t o = ((size_t)problem * a.rows_cap + q) * 2;
         a.knn_idx[o] = k0 == ~0ull ? -1 : (int32_t)(k0 & 0xFFFFFFFFu);
         a.knn_idx[o + 1] = k1 == ~0ull ? -1 : (int32_t)(k1 & 0xFFFFFFFFu);
         a.knn_dist[o] = k0 == ~0ull ? FLT_MAX : __uint_as_float((unsigned)(k0 >> 32));
         a.knn_dist[o + 1] = k1 == ~0ull ? FLT_MAX : __uint_as_float((unsigned)(k1 >> 32));
+    }
+}
+
+// Largest ||t||^2 of the packed rows (non-negative floats order like their bit patterns).
+__global__ void l2_norm_max_kernel(const float* __restrict__ norms, size_t n, float* __restrict__ out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = norms[i];
+        m = v > m ? v : m;   // a NaN norm is skipped; its row never ranks anyway
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+
+// The listed queries against every train row: one workgroup per entry (grid-stride), one train
+// row per lane and step, best two by (sequential distance, train index).
+__global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
+    __shared__ unsigned long long red[2][kBlock / 64];
+    const int count = *a.todo_count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = blockIdx.x; e < count; e += gridDim.x) {
+        const int problem = a.todo[2 * (size_t)e], q = a.todo[2 * (size_t)e + 1];
+        int qf = 0, tf = 0;
+        if (a.pairs) {
+            const int gp = problem >> 1, dir = problem & 1;
+            const int fa = a.pairs[2 * gp], fb = a.pairs[2 * gp + 1];
+            qf = dir ? fb : fa;
+            tf = dir ? fa : fb;
+        }
+        const int nt = a.counts ? a.counts[tf] : a.nt_uniform;
+        const float* qrow = a.q_base + (size_t)qf * a.frame_floats + (size_t)q * a.K;
+        const float* trows = a.t_base + (size_t)tf * a.frame_floats;
+        unsigned long long m0 = ~0ull, m1 = ~0ull;
+        for (int t = threadIdx.x; t < nt; t += kBlock) {
+            float d = sequential_sqr(qrow, trows + (size_t)t * a.K, a.K);
+            if (!a.squared) d = sqrtf(d);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
+            if (key < m0) {
+                m1 = m0;
+                m0 = key;
+            } else if (key < m1) {
+                m1 = key;
+            }
+        }
+        // best two of the workgroup: the smallest, then the smallest of what is left
+        const unsigned long long w0 = wave_min_u64(m0);
+        const unsigned long long mine = m0 == w0 ? m1 : m0;  // keys are distinct (they hold the index)
+        const unsigned long long w1 = wave_min_u64(mine);
+        if (lane == 0) {
+            red[0][wave] = w0;
+            red[1][wave] = w1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long k0 = ~0ull, k1 = ~0ull;
+            for (int w = 0; w < kBlock / 64; ++w)
+                for (int r = 0; r < 2; ++r) {
+                    const unsigned long long key = red[r][w];
+                    if (key < k0) {
+                        k1 = k0;
+                        k0 = key;
+                    } else if (key < k1) {
+                        k1 = key;
+                    }
+                }
+            const size_t o = ((size_t)problem * a.rows_cap + q) * 2;
+            const float d0 = __uint_as_float((unsigned)(k0 >> 32)), d1 = __uint_as_float((unsigned)(k1 >> 32));
+            a.knn_idx[o] = k0 == ~0ull ? -1 : (int32_t)(k0 & 0xFFFFFFFFu);
+            a.knn_idx[o + 1] = k1 == ~0ull ? -1 : (int32_t)(k1 & 0xFFFFFFFFu);
+            a.knn_dist[o] = k0 == ~0ull ? FLT_MAX : d0;
+            a.knn_dist[o + 1] = k1 == ~0ull ? FLT_MAX : d1;
+        }
+        __syncthreads();
     }
 }
 
@@ -439,11 +582,41 @@ int launch_candidates(sfm_ctx* ctx, const L2Args& a, long grid) {
     return SFM_OK;
 }
 
-// Candidate + re-score passes over packed data; writes knn_idx/knn_dist [problem][rows_cap][2].
+// Scratch of one candidate / re-score / exhaustive sequence.
+struct L2Scratch {
+    int32_t* cand;       // [problems][splits][rows_cap][4]
+    float* cand_key;     // same layout
+    float* cand_third;   // [problems][splits][rows_cap][2]
+    float* norm_max;     // one float
+    int32_t* todo_count; // one int
+    int32_t* todo;       // [problems][rows_cap][2]
+    int32_t* knn_idx;    // [problems][rows_cap][2]
+    float* knn_dist;
+};
+void l2_scratch_carve(Carver& c, const L2Plan& plan, int rows_cap, size_t n_problems, L2Scratch* s) {
+    s->cand = c.take<int32_t>(n_problems * plan.splits * rows_cap * 4);
+    s->cand_key = c.take<float>(n_problems * plan.splits * rows_cap * 4);
+    s->cand_third = c.take<float>(n_problems * plan.splits * rows_cap * 2);
+    s->norm_max = c.take<float>(1);
+    s->todo_count = c.take<int32_t>(1);
+    s->todo = c.take<int32_t>(n_problems * rows_cap * 2);
+    s->knn_idx = c.take<int32_t>(n_problems * rows_cap * 2);
+    s->knn_dist = c.take<float>(n_problems * rows_cap * 2);
+}
+
+// SFM_L2_EXHAUSTIVE=1 sends every query through the exhaustive pass (a testing aid, read per call).
+bool l2_force_exhaustive() {
+    const char* e = getenv("SFM_L2_EXHAUSTIVE");
+    return e && e[0] == '1';
+}
+
+// Candidate, re-score and exhaustive passes over packed data; writes s.knn_idx / s.knn_dist
+// [problem][rows_cap][2].  norms: ||row||^2 of every packed row (n_norms of them, rows_cap per
+// frame), used for the queries' norms and, through its maximum, for the error bound.
 int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const float* q_base,
-                  const float* t_base, const float* t_norms, size_t frame_floats, int rows_cap,
-                  const int32_t* d_counts, int nq_uniform, int nt_uniform, const int32_t* d_pairs,
-                  int n_problems, int32_t* cand, float* cand_key, int32_t* knn_idx, float* knn_dist) {
+                  const float* t_base, const float* q_norms, const float* t_norms, size_t n_t_norms,
+                  size_t frame_floats, int rows_cap, const int32_t* d_counts, int nq_uniform, int nt_uniform,
+                  const int32_t* d_pairs, int n_problems, const L2Scratch& s) {
     L2Args a{};
     a.q_base = q_base;
     a.t_base = t_base;
@@ -458,11 +631,20 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     a.qtiles = plan.qtiles;
     a.splits = plan.splits;
     a.blocks_per_group = (d_pairs ? 2 : 1) * plan.qtiles * plan.splits;
-    a.cand = cand;
-    a.cand_key = cand_key;
+    a.cand = s.cand;
+    a.cand_key = s.cand_key;
+    a.cand_third = s.cand_third;
     const long grid = (long)a.n_groups * a.blocks_per_group;
     if (grid <= 0) return SFM_OK;
     if (grid > 0x7fffffffL) return set_error(ctx, SFM_E_INVALID, "knn launch too large");
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(s.norm_max, 0, sizeof(float), ctx->stream));
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(s.todo_count, 0, sizeof(int32_t), ctx->stream));
+    if (n_t_norms > 0) {
+        const int blocks = (int)std::min<size_t>((n_t_norms + 255) / 256, 1024);
+        hipLaunchKernelGGL(l2_norm_max_kernel, dim3(blocks), dim3(256), 0, ctx->stream, t_norms, n_t_norms,
+                           s.norm_max);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
     if (plan.K == 64)
         SFM_RETURN_IF((launch_candidates<64, 2>(ctx, a, grid)));
     else if (plan.K == 128)
@@ -483,14 +665,27 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     r.K = plan.K;
     r.dim = dim;
     r.squared = squared;
-    r.cand = cand;
-    r.cand_key = cand_key;
-    r.knn_idx = knn_idx;
-    r.knn_dist = knn_dist;
+    r.cand = s.cand;
+    r.cand_key = s.cand_key;
+    r.cand_third = s.cand_third;
+    r.q_norms = q_norms;
+    r.t_norm_max = s.norm_max;
+    r.force_exhaustive = l2_force_exhaustive() ? 1 : 0;
+    r.knn_idx = s.knn_idx;
+    r.knn_dist = s.knn_dist;
+    r.todo_count = s.todo_count;
+    r.todo = s.todo;
+    r.stat_exhaustive = ctx->stats;
     const int nq_max = d_counts ? rows_cap : nq_uniform;
     const dim3 rgrid((nq_max + kBlock / 64 - 1) / (kBlock / 64), n_problems);
-    KernelTimer timer(ctx, KID_L2_RESCORE);
-    hipLaunchKernelGGL(l2_rescore_kernel, rgrid, dim3(kBlock), 0, ctx->stream, r);
+    {
+        KernelTimer timer(ctx, KID_L2_RESCORE);
+        hipLaunchKernelGGL(l2_rescore_kernel, rgrid, dim3(kBlock), 0, ctx->stream, r);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    // the listed queries (normally none: the workgroups read a zero count and leave)
+    KernelTimer timer(ctx, KID_L2_EXHAUSTIVE);
+    hipLaunchKernelGGL(l2_exhaustive_kernel, dim3(4 * ctx->num_cus), dim3(kBlock), 0, ctx->stream, r);
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
 }
@@ -520,14 +715,12 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
     const int K = plan.K;
     const int rows_cap = nq > nt ? nq : nt;
     Carver sz(nullptr);
+    L2Scratch sc;
     sz.take<float>((size_t)nq * K);
     sz.take<float>((size_t)(nt > 0 ? nt : 1) * K);
     sz.take<float>((size_t)rows_cap);
     sz.take<float>((size_t)rows_cap);
-    sz.take<int32_t>((size_t)plan.splits * rows_cap * 4);
-    sz.take<float>((size_t)plan.splits * rows_cap * 4);
-    sz.take<int32_t>((size_t)rows_cap * 2);
-    sz.take<float>((size_t)rows_cap * 2);
+    l2_scratch_carve(sz, plan, rows_cap, 1, &sc);
     void* ws;
     SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
     Carver c(ws);
@@ -535,17 +728,15 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
     float* tp = c.take<float>((size_t)(nt > 0 ? nt : 1) * K);
     float* qn = c.take<float>((size_t)rows_cap);
     float* tn = c.take<float>((size_t)rows_cap);
-    int32_t* cand = c.take<int32_t>((size_t)plan.splits * rows_cap * 4);
-    float* ckey = c.take<float>((size_t)plan.splits * rows_cap * 4);
-    int32_t* kidx = c.take<int32_t>((size_t)rows_cap * 2);
-    float* kdist = c.take<float>((size_t)rows_cap * 2);
+    l2_scratch_carve(c, plan, rows_cap, 1, &sc);
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(ctx->stats, 0, sizeof(int32_t), ctx->stream));
     SFM_RETURN_IF(l2_pack(ctx, d_q, nq, q_stride, dim, qp, K, qn));
     SFM_RETURN_IF(l2_pack(ctx, d_t, nt, t_stride, dim, tp, K, tn));
-    SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, qp, tp, tn, 0, rows_cap, nullptr, nq, nt,
-                                nullptr, 1, cand, ckey, kidx, kdist));
-    SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, kidx, sizeof(int32_t) * 2 * nq, hipMemcpyDeviceToDevice,
+    SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, qp, tp, qn, tn, (size_t)nt, 0, rows_cap, nullptr, nq,
+                                nt, nullptr, 1, sc));
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, sc.knn_idx, sizeof(int32_t) * 2 * nq, hipMemcpyDeviceToDevice,
                                       ctx->stream));
-    SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_dist, kdist, sizeof(float) * 2 * nq, hipMemcpyDeviceToDevice,
+    SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_dist, sc.knn_dist, sizeof(float) * 2 * nq, hipMemcpyDeviceToDevice,
                                       ctx->stream));
     return SFM_OK;
 }
@@ -554,10 +745,7 @@ namespace {
 struct L2PairBuffers {
     float* packed;
     float* norms;
-    int32_t* cand;
-    float* cand_key;
-    int32_t* kidx;
-    float* kdist;
+    L2Scratch sc;
     int32_t* best;
     float* best_dist;
 };
@@ -566,10 +754,7 @@ void l2_pairs_carve(Carver& c, const L2Plan& plan, int n_frames, int rows, int n
     b->packed = c.take<float>((size_t)n_frames * rows * plan.K);
     b->norms = c.take<float>((size_t)n_frames * rows);
     const size_t nprob = 2 * (size_t)n_pairs;
-    b->cand = c.take<int32_t>(nprob * plan.splits * rows * 4);
-    b->cand_key = c.take<float>(nprob * plan.splits * rows * 4);
-    b->kidx = c.take<int32_t>(nprob * rows * 2);
-    b->kdist = c.take<float>(nprob * rows * 2);
+    l2_scratch_carve(c, plan, rows, nprob, &b->sc);
     b->best = c.take<int32_t>(nprob * rows);
     b->best_dist = c.take<float>(nprob * rows);
 }
@@ -606,6 +791,7 @@ int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_fr
     SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
     Carver c(ws);
     l2_pairs_carve(c, plan, n_frames, rows_per_frame, chunk, &b);
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(ctx->stats, 0, sizeof(int32_t), ctx->stream));
     for (int f = 0; f < n_frames; ++f)
         SFM_RETURN_IF(l2_pack(ctx, reinterpret_cast<const uint8_t*>(d_desc) + f * frame_stride,
                               rows_per_frame, (size_t)dim * 4, dim,
@@ -614,11 +800,11 @@ int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_fr
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
         const int np = chunk < n_pairs - p0 ? chunk : n_pairs - p0;
         const int32_t* pairs = d_pairs + 2 * (size_t)p0;
-        SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, b.packed, b.packed, b.norms,
-                                    (size_t)rows_per_frame * plan.K, rows_per_frame, d_counts,
-                                    rows_per_frame, rows_per_frame, pairs, 2 * np, b.cand, b.cand_key,
-                                    b.kidx, b.kdist));
-        SFM_RETURN_IF(launch_ratio_cross_knn(ctx, b.kidx, b.kdist, rows_per_frame, d_counts,
+        SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, b.packed, b.packed, b.norms, b.norms,
+                                    (size_t)n_frames * rows_per_frame, (size_t)rows_per_frame * plan.K,
+                                    rows_per_frame, d_counts, rows_per_frame, rows_per_frame, pairs, 2 * np,
+                                    b.sc));
+        SFM_RETURN_IF(launch_ratio_cross_knn(ctx, b.sc.knn_idx, b.sc.knn_dist, rows_per_frame, d_counts,
                                              rows_per_frame, pairs, np, ratio, b.best, b.best_dist,
                                              d_matches + (size_t)p0 * cap, cap,
                                              d_match_counts + p0));

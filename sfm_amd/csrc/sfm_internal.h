@@ -45,6 +45,7 @@ enum KernelId {
     KID_HAMMING_MFMA,
     KID_HAMMING_EXPAND,
     KID_COMPACT_MATCHES,
+    KID_L2_EXHAUSTIVE,
     KID_COUNT
 };
 struct TimedLaunch {
@@ -64,6 +65,8 @@ struct sfm_ctx {
     void* pinned = nullptr;   // grow-only page-locked host buffer for gathering strided rows
     size_t pinned_bytes = 0;
     size_t pinned_used = 0;   // bytes handed out since the stream was last idle
+    int32_t* stats = nullptr; // small device buffer of counters kernels add to ([0]: L2 queries sent
+                              // through the exhaustive pass by the last L2 entry point)
     int num_cus = 256;
     std::string err;
     bool profiling = false;

@@ -130,3 +130,110 @@ def test_matcher_mirror_class(ctx, oracle):
     pa, pb, matches, ia, ib = m.findRobustMatches(kp_a, kp_b, a, b, useEpipolarFilter=True)
     _, _, mask, _ = oracle.find_fundamental(kp_a[want["queryIdx"]], kp_b[want["trainIdx"]])
     assert _tuples(matches) == _tuples(want[mask.astype(bool)])
+
+
+def _near_tie_sets(dim, nq, nt, seed, unit):
+    """Train sets built to defeat candidate selection by an approximate key: for every query,
+    24 train rows that equal its true second neighbour up to +-1 ulp in a few components, placed
+    at indices that share one candidate list (multiples of 8), plus exact duplicates of it."""
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    t = rng.standard_normal((nt, dim)).astype(np.float32)
+    if unit:
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        t /= np.linalg.norm(t, axis=1, keepdims=True)
+    else:
+        q, t = np.round(q * 40), np.round(t * 40)     # integer-valued, SIFT-like magnitudes
+    q, t = q.astype(np.float32), t.astype(np.float32)
+    span = nt // nq                                   # query i's rows sit in [i*span, (i+1)*span):
+    assert span >= 26 * 8                             # one train split, one lane half (index % 8 == 0)
+    slots = np.stack([i * span + 8 * rng.permutation(span // 8)[:26] for i in range(nq)])
+    for i in range(nq):
+        near = q[i] + (0.05 if unit else 3.0) * rng.standard_normal(dim).astype(np.float32)
+        if not unit:
+            near = np.round(near)
+        near = near.astype(np.float32)
+        t[slots[i, 0]] = q[i] + (0.01 if unit else 1.0) * np.sign(rng.standard_normal(dim)).astype(np.float32)
+        for k in range(1, 25):
+            row = near.copy()
+            j = rng.integers(0, dim, size=3)
+            row[j] = np.nextafter(row[j], np.float32(np.inf) * np.sign(rng.standard_normal(3)).astype(np.float32))
+            t[slots[i, k]] = row
+        t[slots[i, 25]] = t[slots[i, 7]]              # an exact duplicate among the near ties
+    return q, t
+
+
+@pytest.mark.parametrize("dim", [64, 128])
+@pytest.mark.parametrize("squared", [True, False])
+@pytest.mark.parametrize("unit", [True, False])
+def test_l2_near_ties_in_one_candidate_list(ctx, oracle, dim, squared, unit):
+    """Two dozen train rows within an ulp of the second neighbour, all in one candidate list:
+    more than the matrix-core pass keeps or re-scores.  Indices and distances must still be the
+    oracle's (sequential sum, lower index first), through the exhaustive pass where needed."""
+    from sfm_amd import capi
+
+    q, t = _near_tie_sets(dim, 40, 16000, seed=dim + 2 * squared + unit, unit=unit)
+    norm = capi.NORM_L2SQR if squared else capi.NORM_L2
+    idx, dist = ctx.knn2(norm, q, t)
+    n_exhaustive = ctx.l2_exhaustive_count()
+    oidx, odist = oracle.knn2_l2(q, t, squared=squared)
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_array_equal(dist, odist)
+    assert n_exhaustive >= 30          # the proof fails for (nearly) every query here
+
+
+def test_l2_exhaustive_pass_alone(ctx, oracle, monkeypatch):
+    """SFM_L2_EXHAUSTIVE=1 sends every query through the exhaustive pass; on ordinary data the
+    proof succeeds for all but a few queries and the pass stays idle."""
+    from sfm_amd import capi, synth
+
+    q, t = synth.float_descriptors(700, 3001, dim=128, seed=17, integer=False)
+    t[100] = t[7]
+    oidx, odist = oracle.knn2_l2(q, t, squared=False)
+    idx, dist = ctx.knn2(capi.NORM_L2, q, t)
+    assert ctx.l2_exhaustive_count() <= 7
+    np.testing.assert_array_equal(idx, oidx)
+    monkeypatch.setenv("SFM_L2_EXHAUSTIVE", "1")
+    idx, dist = ctx.knn2(capi.NORM_L2, q, t)
+    assert ctx.l2_exhaustive_count() == 700
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_array_equal(dist, odist)
+    a, b = synth.float_descriptors(600, 500, dim=64, seed=3, integer=True)
+    got = ctx.robust_matches(capi.NORM_L2SQR, a, b, 0.6)
+    assert ctx.l2_exhaustive_count() == 1100
+    want = oracle.robust_matches(oracle.NORM_L2SQR, a, b, 0.6)
+    assert _tuples(got) == _tuples(want)
+
+
+@pytest.mark.parametrize("integer", [True, False])
+def test_l2_full_size_20000x20000x128(ctx, oracle, integer):
+    """The float-matching configuration at the size it is quoted on (20 000 x 20 000 x 128, both
+    variants): 500 query rows spread over the set are checked bit for bit against the oracle run
+    on those rows against the full train set; all rows are checked for the properties of a 2-NN
+    result (valid distinct indices, ordered distances, the reported distances recomputed)."""
+    import torch
+
+    from sfm_amd import capi, synth
+
+    n, dim = 20000, 128
+    q, t = synth.float_descriptors(n, n, dim=dim, seed=99, integer=integer)
+    dev = torch.device("cuda", 0)
+    d_q, d_t = torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev)
+    d_idx = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    d_dist = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    ctx.knn2_dev(capi.NORM_L2, d_q, n, dim * 4, d_t, n, dim * 4, dim, d_idx, d_dist)
+    ctx.synchronize()
+    idx, dist = d_idx.cpu().numpy(), d_dist.cpu().numpy()
+    assert ctx.l2_exhaustive_count() < n // 100
+    assert (idx >= 0).all() and (idx < n).all() and (idx[:, 0] != idx[:, 1]).all()
+    assert (dist[:, 0] <= dist[:, 1]).all() and np.isfinite(dist).all()
+    ties = dist[:, 0] == dist[:, 1]
+    assert (idx[ties, 0] < idx[ties, 1]).all()
+    # the reported distances are the distances to the reported rows (float64 check of all rows)
+    for k in range(2):
+        d64 = np.sqrt(((q.astype(np.float64) - t[idx[:, k]].astype(np.float64)) ** 2).sum(1))
+        np.testing.assert_allclose(dist[:, k], d64, rtol=2e-6, atol=1e-6)
+    rows = np.linspace(0, n - 1, 500).astype(np.int64)
+    oidx, odist = oracle.knn2_l2(q[rows], t, squared=False)
+    np.testing.assert_array_equal(idx[rows], oidx)
+    np.testing.assert_array_equal(dist[rows], odist)
