@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
             const int ti = tbase + 32 * mt + 8 * gq + 4 * lh + r;
             const bool c0 = key < best0[n], c1 = key < best1[n];
             // the key that does not stay in the list, max(key, old second), may be the new third
-            third[n] = __builtin_amdgcn_fmed3f(third[n], key, best1[n]);
+            asm("v_med3_f32 %0, %0, %1, %2" : "+v"(third[n]) : "v"(key), "v"(best1[n]));
             const float t = c1 ? key : best1[n];
             const int tix = c1 ? ti : bidx1[n];
             best1[n] = c0 ? best0[n] : t;
