@@ -92,6 +92,12 @@ def parse():
                          "frame-pair workload, 32 for f1 / f2 / f3 / vo")
     ap.add_argument("--frames", type=int, default=512, help="c5: frames in the window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain", type=float, default=2.0,
+                    help="framepair: seconds the step is looped after the timed region for the "
+                         "'sustained' rate (0: off)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="framepair: skip the short runs of the other configurations "
+                         "(triangulation, float matching, sharded window) reported under 'other_configs'")
     ap.add_argument("--overlap", action="store_true",
                     help="framepair: tracking on a second HIP stream, concurrent with matching "
                          "(+4 %% throughput; per-kernel event times then include the overlap, so "
@@ -329,6 +335,26 @@ def run_framepair(args, rank, world, local):
                            () if ctx_lk is ctx else (ctx_lk,))
     feats_step = world * P * (2 * KPS + LK_POINTS)
     value = feats_step * args.steps / dt
+    # the same step looped for at least --sustain seconds: a rate at the clock the chip holds
+    # under continuous load, beside the short timed region's
+    sustained = None
+    if args.sustain > 0:
+        barrier_sync(world)
+        t0, n_sus = time.perf_counter(), 0
+        while True:
+            for _ in range(10):
+                step()
+            n_sus += 10
+            torch.cuda.synchronize()
+            go_on = torch.tensor([1.0 if time.perf_counter() - t0 < args.sustain else 0.0], device=dev)
+            if world > 1:   # every rank leaves the loop after the same number of steps
+                torch.distributed.all_reduce(go_on, op=torch.distributed.ReduceOp.MIN)
+            if go_on.item() == 0.0:
+                break
+        barrier_sync(world)
+        dt_sus = max_over_ranks(time.perf_counter() - t0, world, dev)
+        sustained = {"value": round(feats_step * n_sus / dt_sus, 1), "unit": "features/s", "steps": n_sus,
+                     "seconds": round(dt_sus, 3), "ms_per_step": round(1e3 * dt_sus / n_sus, 4)}
     matched = int(d_mcount.sum().item())
     if gather is not None:
         gathered["n"] = int(gather.counts.sum().item())
@@ -371,6 +397,8 @@ def run_framepair(args, rank, world, local):
         "check": {"cross_checked_matches_per_step": matched, "tracked_per_step": tracked,
                   "gathered_matches": gathered.get("n")},
     }
+    if sustained is not None:
+        out["sustained"] = sustained
     if lk_n:
         out["lk_track"] = {"avg_launch_us": round(1e3 * lk_ms / lk_n, 2),
                            "points_per_s": round(P * LK_POINTS / (lk_ms / lk_n * 1e-3), 1)}
@@ -957,6 +985,27 @@ def run_vo(args, rank, world, local):
     return out
 
 
+def other_configs(args, rank, world, local):
+    """Short runs of the other configurations, so that one default invocation carries a measured
+    line for each: triangulation (10 M correspondences) and float matching (20 000^2 x 128) on
+    rank 0's GPU only (they do not shard: replicas), and the sharded matching window over all
+    ranks (strong scaling: the window is fixed, pairs are dealt over the ranks)."""
+    import copy
+
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "config",
+            "roofline", "cpu_baseline", "check", "ms_per_frame_pair", "kernels")
+    res = {}
+    a = copy.copy(args)
+    a.steps, a.warmup, a.frames = 3, 1, 192
+    res["c5_window"] = {k: v for k, v in run_c5(a, rank, world, local).items() if k in keep}
+    if world == 1:
+        a = copy.copy(args)
+        a.steps, a.warmup = 10, 2
+        res["c3"] = {k: v for k, v in run_c3(a, rank, world, local).items() if k in keep}
+        res["c4"] = {k: v for k, v in run_c4(a, rank, world, local).items() if k in keep}
+    return res
+
+
 def spawn_ranks(args):
     """--gpus N without a launcher: start N ranks as a child `torch.distributed.run` (fresh
     processes; this parent never initialises the GPU and is not replaced), forward the one JSON
@@ -1018,6 +1067,8 @@ def main():
     rank, world, local = dist_setup(args.gpus, args.force_gather)
     run = {"framepair": run_framepair, "c3": run_c3, "c4": run_c4, "c5": run_c5, "f1": run_f1, "f2": run_f2, "f3": run_f3, "vo": run_vo}[args.workload]
     out = run(args, rank, world, local)
+    if args.workload == "framepair" and not args.no_other_configs:
+        out["other_configs"] = other_configs(args, rank, world, local)
     if rank == 0:
         print(json.dumps(out))
     if world > 1 or args.force_gather:

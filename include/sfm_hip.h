@@ -397,7 +397,8 @@ int sfm_recover_pose(sfm_ctx* ctx, const double* E, const float* pts1, const flo
 /* Many device-resident point sets per call.  d_E: problem p's matrix at d_E + p * E_stride
  * doubles (E_stride 90 chains after sfm_find_essential_dev); d_found (optional): a problem is
  * only processed when its entry is exactly 1; max_first_residual > 0 adds the reference's
- * test | p1^T K^-T E K^-1 p0 | <= limit on the first correspondence (Source Files/
+ * tests: more than five correspondences (Source Files/tracking.cpp:92) and
+ * | p1^T K^-T E K^-1 p0 | <= limit on the first correspondence (Source Files/
  * tracking.cpp:99-107, 1e-3 there).  Problems that are skipped get d_good = 0. */
 int sfm_recover_pose_dev(sfm_ctx* ctx, const double* d_E, size_t E_stride, const int32_t* d_found,
                          const float* d_pts1, const float* d_pts2, size_t problem_stride, const int32_t* d_counts,

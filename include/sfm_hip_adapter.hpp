@@ -230,8 +230,8 @@ public:
                            cvx::Mat prevDesc, cvx::Mat currDesc, std::vector<cvx::Point2f>& prevAligPts,
                            std::vector<cvx::Point2f>& currAligPts, std::vector<cvx::DMatch>& matches,
                            std::vector<int>& prevPtsToKeyIdx, std::vector<int>& currPtsToKeyIdx,
-                           cvx::Mat /*debugPrevFrame*/ = cvx::Mat(), cvx::Mat /*debugCurrFrame*/ = cvx::Mat(),
-                           bool useEpipolarFilter = false) {
+                           cvx::Mat /*debugPrevFrame*/, cvx::Mat /*debugCurrFrame*/,
+                           bool useEpipolarFilter) {
         if (!prevDesc.empty() && !currDesc.empty()) {
             const int d = checkedDim(prevDesc, currDesc);
             std::vector<cvx::DMatch> cross(size_t(std::min(prevDesc.rows, currDesc.rows)));

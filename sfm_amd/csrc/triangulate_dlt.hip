@@ -653,7 +653,9 @@ __global__ void pose_decompose_kernel(PoseArgs a) {
     if (p >= a.n_problems) return;
     for (int k = 0; k < 4; ++k) a.good[4 * p + k] = 0;
     const int count = pose_count(a, p);
-    int ok = (!a.found || a.found[p] == 1) && count > 0;
+    // with the reference's checks on (max_first_residual > 0) also its early return for five
+    // points or fewer (Source Files/tracking.cpp:92)
+    int ok = (!a.found || a.found[p] == 1) && count > (a.max_first_residual > 0 ? 5 : 0);
     const double* E = a.E + (size_t)p * a.E_stride;
     if (ok && a.max_first_residual > 0) {
         // | p1^T K^-T E K^-1 p0 | of the first correspondence (Source Files/tracking.cpp:99-107)

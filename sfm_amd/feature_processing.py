@@ -77,7 +77,7 @@ class DescriptorMatcher:
         return self.ctx.ratio_matches(self.norm, lDesc, rDesc, float(self.m_ratioThreshold))
 
     def findRobustMatches(self, prevKeyPts, currKeyPts, prevDesc, currDesc,
-                          useEpipolarFilter=False):
+                          useEpipolarFilter):
         """feature_processing.cpp:144-226.
 
         Returns (prevAligPts, currAligPts, matches, prevPtsToKeyIdx, currPtsToKeyIdx), i.e.

@@ -166,6 +166,9 @@ def test_find_camera_pose_batched_on_device(ctx, oracle):
     import torch
 
     sets = [two_view(1200, 71, 0.3), two_view(800, 72, 0.1), two_view(5, 73, 0.0), two_view(300, 74, 0.2)]
+    # five points: the direct solve yields 0..10 matrices; whatever their number (also exactly
+    # one) the reference has already returned false (tracking.cpp:92)
+    sets += [two_view(5, 80 + k, 0.0) for k in range(12)]
     stride, P = 1200, len(sets)
     K = sets[0][3]["K"]
     pts1 = np.zeros((P, stride, 2), np.float32)
@@ -188,10 +191,12 @@ def test_find_camera_pose_batched_on_device(ctx, oracle):
     for k, (a, b, _, _) in enumerate(sets):
         n = len(a)
         oE, omask, _ = oracle.find_essential(a, b, K, 0, 0.99, 0.5)
-        if len(oE) != 1 or oracle.essential_residual(oE[0], a[0], b[0], K) > 1e-3:
+        if n <= 5 or len(oE) != 1 or oracle.essential_residual(oE[0], a[0], b[0], K) > 1e-3:
             assert inl[k] == 0
             continue
         ocnt, oR, ot, omask2 = oracle.recover_pose(oE[0], a, b, K, omask)
         assert inl[k] == ocnt
         np.testing.assert_array_equal(masks[k, :n], omask2)
         np.testing.assert_allclose(Rs[k].reshape(3, 3), oR, atol=1e-8)
+    founds = df.cpu().numpy()
+    assert (founds[counts == 5] >= 0).all() and (inl[counts == 5] == 0).all()
