@@ -46,6 +46,7 @@
 #include <opencv2/calib3d.hpp>
 #include <opencv2/core.hpp>
 #include <opencv2/features2d.hpp>
+#include <opencv2/video/tracking.hpp>
 namespace sfm_hip {
 namespace cvx = cv;
 inline bool mat_is_u8(const cv::Mat& m) { return m.depth() == CV_8U; }
@@ -62,7 +63,6 @@ namespace sfm_hip {
 /* Stand-ins for the OpenCV types at the boundary: same member names, and for
  * the plain structs the same layout, as OpenCV 4's. */
 namespace cvx {
-typedef unsigned char uchar;
 struct Point2f {
     float x, y;
     Point2f() : x(0), y(0) {}
@@ -93,7 +93,7 @@ struct Vec {
     const T& operator[](int i) const { return val[i]; }
 };
 typedef Vec<double, 3> Vec3d;
-typedef Vec<uchar, 3> Vec3b;
+typedef Vec<unsigned char, 3> Vec3b;
 template <int R, int C>
 struct Matx {
     double val[R * C];
@@ -116,20 +116,31 @@ struct Mat {
     enum Depth { U8 = 0, F32 = 5 };
     int rows, cols, depth_, channels_;
     size_t step;
-    uchar* data;
-    std::shared_ptr<std::vector<uchar>> storage;
+    unsigned char* data;
+    std::shared_ptr<std::vector<unsigned char>> storage;
     Mat() : rows(0), cols(0), depth_(U8), channels_(1), step(0), data(nullptr) {}
     Mat(int r, int c, Depth d, int ch = 1)
         : rows(r), cols(c), depth_(d), channels_(ch),
           step(size_t(c) * ch * (d == F32 ? 4 : 1)),
-          storage(std::make_shared<std::vector<uchar>>(size_t(r) * step)) {
+          storage(std::make_shared<std::vector<unsigned char>>(size_t(r) * step)) {
         data = storage->data();
     }
     /* Wraps memory the caller keeps alive. */
     Mat(int r, int c, Depth d, int ch, void* p, size_t step_bytes)
-        : rows(r), cols(c), depth_(d), channels_(ch), step(step_bytes), data(static_cast<uchar*>(p)) {}
+        : rows(r), cols(c), depth_(d), channels_(ch), step(step_bytes), data(static_cast<unsigned char*>(p)) {}
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
 };
+template <typename T>
+using Ptr = std::shared_ptr<T>;
+/* The three calls FeatureDetector::generateFeatures makes on cv::Feature2D. */
+struct Feature2D {
+    virtual ~Feature2D() {}
+    virtual void detect(const Mat& image, std::vector<KeyPoint>& keypoints) = 0;
+    virtual void compute(const Mat& image, std::vector<KeyPoint>& keypoints, Mat& descriptors) = 0;
+    virtual void detectAndCompute(const Mat& image, const Mat& mask, std::vector<KeyPoint>& keypoints,
+                                  Mat& descriptors) = 0;
+};
+inline Mat noArray() { return Mat(); }
 }  // namespace cvx
 inline bool mat_is_u8(const cvx::Mat& m) { return m.depth_ == cvx::Mat::U8; }
 inline bool mat_is_f32(const cvx::Mat& m) { return m.depth_ == cvx::Mat::F32; }
@@ -323,7 +334,7 @@ class OptFlow {
 public:
     PyrLKSettings optFlow;
     OptFlowAddSettings additionalSettings;
-    std::vector<cvx::uchar> statusMask;
+    std::vector<unsigned char> statusMask; /* std::vector<uchar> in the reference */
     Handle handle;
 
     /* Source Files/feature_processing.cpp:228-236. */
@@ -344,7 +355,7 @@ public:
 
     /* Source Files/feature_processing.cpp:238-249. */
     void computeFlow(cvx::Mat imPrevGray, cvx::Mat imCurrGray, std::vector<cvx::Point2f>& prevPts,
-                     std::vector<cvx::Point2f>& currPts, std::vector<cvx::uchar>& statusMask_) {
+                     std::vector<cvx::Point2f>& currPts, std::vector<unsigned char>& statusMask_) {
         const size_t n = prevPts.size();
         currPts.resize(n);
         statusMask_.resize(n);
@@ -365,15 +376,34 @@ public:
     }
 };
 
-/* Header Files/feature_processing.h:8-31, the member on the tracker's path:
- * generateFlowFeatures (Source Files/feature_processing.cpp:87-99).  The key point
- * detectors / extractors of generateFeatures are OpenCV's own and stay with it: keep the
- * reference's class for those and forward this one member, or use this class where only
- * flow features are generated. */
+/* Header Files/feature_processing.h:8-31.  generateFlowFeatures
+ * (Source Files/feature_processing.cpp:87-99) runs on the GPU.  The key point detectors and
+ * extractors of generateFeatures are OpenCV's own CPU code and stay with it: the public
+ * `detector` / `extractor` handles are kept, the caller supplies them (the reference's
+ * constructor picks them by name from OpenCV + opencv_contrib, :26-74), and
+ * generateFeatures forwards to them exactly as Source Files/feature_processing.cpp:77-85
+ * does. */
 class FeatureDetector {
 public:
+    cvx::Ptr<cvx::Feature2D> detector, extractor;
     Handle handle;
+
     explicit FeatureDetector(std::string /*method*/ = "AKAZE", Handle h = Handle::shared()) : handle(h) {}
+    FeatureDetector(std::string /*method*/, cvx::Ptr<cvx::Feature2D> detector_, cvx::Ptr<cvx::Feature2D> extractor_,
+                    Handle h = Handle::shared())
+        : detector(detector_), extractor(extractor_), handle(h) {}
+
+    /* Source Files/feature_processing.cpp:77-85. */
+    void generateFeatures(cvx::Mat& imGray, std::vector<cvx::KeyPoint>& keyPts, cvx::Mat& descriptor) {
+        if (!detector || !extractor)
+            raise("FeatureDetector::generateFeatures needs detector and extractor to be set (OpenCV's own objects)");
+        if (detector != extractor) {
+            detector->detect(imGray, keyPts);
+            extractor->compute(imGray, keyPts, descriptor);
+        } else {
+            detector->detectAndCompute(imGray, cvx::noArray(), keyPts, descriptor);
+        }
+    }
 
     /* cv::goodFeaturesToTrack(imGray, _corners, maxCorners, qualityLevel, minDistance);
      * new corners are appended, points already in `corners` are kept. */
@@ -515,6 +545,120 @@ private:
     const bool m_useNormalizePts;
     Handle handle;
 };
+
+#ifdef SFM_ADAPTER_HAVE_OPENCV
+/* ---- Seam 2: OpenCV's own operator interfaces ---------------------------------------------
+ * DescriptorMatcher::matcher and OptFlow::optFlow are public cv::Ptr members of the reference's
+ * wrappers (Header Files/feature_processing.h:44, :79).  A maintainer who keeps the wrappers
+ * as they are can assign these instead of cv::DescriptorMatcher::create(...) /
+ * cv::SparsePyrLKOpticalFlow::create(...):
+ *     descMatcher.matcher = cv::makePtr<sfm_hip::HipBFMatcher>(cv::NORM_HAMMING);
+ *     optFlow.optFlow     = cv::makePtr<sfm_hip::HipSparsePyrLK>(cv::Size(21, 21), 3, crit);
+ * The wrappers' own host loops (ratio test, cross-check, error gate) then run unchanged. */
+
+/* cv::BFMatcher(normType, crossCheck = false) for k = 2 without masks: what
+ * matcher->knnMatch(lDesc, rDesc, knnMatches, 2) needs (Source Files/feature_processing.cpp:121). */
+class HipBFMatcher : public cv::DescriptorMatcher {
+public:
+    explicit HipBFMatcher(int cvNormType, Handle h = Handle::shared()) : cvNorm_(cvNormType), handle_(h) {
+        if (cvNormType == cv::NORM_HAMMING) norm_ = SFM_NORM_HAMMING;
+        else if (cvNormType == cv::NORM_L2) norm_ = SFM_NORM_L2;
+        else if (cvNormType == cv::NORM_L2SQR) norm_ = SFM_NORM_L2SQR;
+        else CV_Error(cv::Error::StsBadArg, "HipBFMatcher: NORM_HAMMING, NORM_L2 or NORM_L2SQR");
+    }
+    bool isMaskSupported() const override { return false; }
+    cv::Ptr<cv::DescriptorMatcher> clone(bool emptyTrainData = false) const override {
+        cv::Ptr<HipBFMatcher> m = cv::makePtr<HipBFMatcher>(cvNorm_, handle_);
+        if (!emptyTrainData) m->trainDescCollection = trainDescCollection;
+        return m;
+    }
+
+protected:
+    void knnMatchImpl(cv::InputArray queryDescriptors, std::vector<std::vector<cv::DMatch>>& matches, int k,
+                      cv::InputArrayOfArrays masks = cv::noArray(), bool compactResult = false) override {
+        if (k != 2 || trainDescCollection.size() != 1 || !masks.empty())
+            CV_Error(cv::Error::StsNotImplemented, "HipBFMatcher: k = 2, one train image, no masks");
+        const cv::Mat Q = queryDescriptors.getMat(), T = trainDescCollection[0];
+        matches.clear();
+        if (Q.empty()) return;
+        if (Q.channels() != 1 || T.channels() != 1 || (!T.empty() && (Q.cols != T.cols || Q.depth() != T.depth())) ||
+            Q.depth() != (norm_ == SFM_NORM_HAMMING ? CV_8U : CV_32F))
+            CV_Error(cv::Error::StsBadArg, "HipBFMatcher: descriptor type or width does not suit the norm");
+        std::vector<int32_t> idx(2 * size_t(Q.rows));
+        std::vector<float> dist(2 * size_t(Q.rows));
+        const size_t t_step = T.empty() ? size_t(Q.step[0]) : size_t(T.step[0]);
+        handle_.check(sfm_knn2(handle_.get(), norm_, Q.data, Q.rows, Q.step[0], T.data, T.rows, t_step, Q.cols,
+                               idx.data(), dist.data()),
+                      "sfm_knn2");
+        matches.reserve(size_t(Q.rows));
+        for (int i = 0; i < Q.rows; ++i) {
+            std::vector<cv::DMatch> row;
+            for (int j = 0; j < 2 && idx[2 * size_t(i) + j] >= 0; ++j)
+                row.push_back(cv::DMatch(i, idx[2 * size_t(i) + j], 0, dist[2 * size_t(i) + j]));
+            if (!compactResult || !row.empty()) matches.push_back(row);
+        }
+    }
+    void radiusMatchImpl(cv::InputArray, std::vector<std::vector<cv::DMatch>>&, float,
+                         cv::InputArrayOfArrays = cv::noArray(), bool = false) override {
+        CV_Error(cv::Error::StsNotImplemented, "HipBFMatcher: radius matching is not on the reference's path");
+    }
+
+private:
+    int cvNorm_, norm_;
+    Handle handle_;
+};
+
+/* cv::SparsePyrLKOpticalFlow with flags 0 (Source Files/feature_processing.cpp:229, :241). */
+class HipSparsePyrLK : public cv::SparsePyrLKOpticalFlow {
+public:
+    HipSparsePyrLK(cv::Size winSize = cv::Size(21, 21), int maxLevel = 3,
+                   cv::TermCriteria crit = cv::TermCriteria(cv::TermCriteria::COUNT + cv::TermCriteria::EPS, 30, 0.01),
+                   int flags = 0, double minEigThreshold = 1e-4, Handle h = Handle::shared())
+        : winSize_(winSize), maxLevel_(maxLevel), crit_(crit), flags_(flags), minEig_(minEigThreshold), handle_(h) {}
+
+    cv::Size getWinSize() const override { return winSize_; }
+    void setWinSize(cv::Size winSize) override { winSize_ = winSize; }
+    int getMaxLevel() const override { return maxLevel_; }
+    void setMaxLevel(int maxLevel) override { maxLevel_ = maxLevel; }
+    cv::TermCriteria getTermCriteria() const override { return crit_; }
+    void setTermCriteria(cv::TermCriteria& crit) override { crit_ = crit; }
+    int getFlags() const override { return flags_; }
+    void setFlags(int flags) override { flags_ = flags; }
+    double getMinEigThreshold() const override { return minEig_; }
+    void setMinEigThreshold(double minEigThreshold) override { minEig_ = minEigThreshold; }
+
+    void calc(cv::InputArray prevImg, cv::InputArray nextImg, cv::InputArray prevPts, cv::InputOutputArray nextPts,
+              cv::OutputArray status, cv::OutputArray err = cv::noArray()) override {
+        if (flags_ != 0) CV_Error(cv::Error::StsNotImplemented, "HipSparsePyrLK: flags must be 0");
+        const cv::Mat prev = prevImg.getMat(), next = nextImg.getMat(), pts = prevPts.getMat();
+        const int n = int(pts.total());
+        if (pts.type() != CV_32FC2 || !pts.isContinuous())
+            CV_Error(cv::Error::StsBadArg, "HipSparsePyrLK: points must be a continuous array of Point2f");
+        nextPts.create(pts.size(), pts.type(), -1, true);
+        status.create(n, 1, CV_8U, -1, true);
+        if (err.needed()) err.create(n, 1, CV_32F, -1, true);
+        if (n == 0) return;
+        if (prev.type() != CV_8UC1 || next.type() != CV_8UC1 || prev.rows != next.rows || prev.cols != next.cols ||
+            prev.step[0] != next.step[0])
+            CV_Error(cv::Error::StsBadArg, "HipSparsePyrLK: two 8-bit single-channel images of one size and pitch");
+        cv::Mat out = nextPts.getMat(), st = status.getMat(), er = err.needed() ? err.getMat() : cv::Mat();
+        /* no error gate here: OptFlow::computeFlow applies its own (feature_processing.cpp:245-248) */
+        handle_.check(sfm_pyrlk(handle_.get(), prev.data, next.data, prev.cols, prev.rows, prev.step[0],
+                                pts.ptr<float>(), n, winSize_.width, winSize_.height, maxLevel_, crit_.type,
+                                crit_.maxCount, crit_.epsilon, minEig_, 3.402823466e+38f, out.ptr<float>(),
+                                st.ptr<unsigned char>(), er.empty() ? nullptr : er.ptr<float>()),
+                      "sfm_pyrlk");
+    }
+
+private:
+    cv::Size winSize_;
+    int maxLevel_;
+    cv::TermCriteria crit_;
+    int flags_;
+    double minEig_;
+    Handle handle_;
+};
+#endif /* SFM_ADAPTER_HAVE_OPENCV */
 
 }  // namespace sfm_hip
 #endif /* SFM_HIP_ADAPTER_HPP */

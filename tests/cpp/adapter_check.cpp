@@ -245,6 +245,33 @@ static int run_errors() {
         noFilter.epipolarFilter = nullptr;
         noFilter.findRobustMatches(kp, kp, u8, u8, a, b, m, ia, ib, cvx::Mat(), cvx::Mat(), true);
     });
+    // generateFeatures forwards to the caller's detector / extractor as the reference does
+    // (feature_processing.cpp:77-85): one object -> detectAndCompute, two -> detect + compute
+    {
+        struct Counting : cvx::Feature2D {
+            int detects = 0, computes = 0, both = 0;
+            void detect(const cvx::Mat&, std::vector<cvx::KeyPoint>& k) override { ++detects; k.resize(3); }
+            void compute(const cvx::Mat&, std::vector<cvx::KeyPoint>&, cvx::Mat& d) override {
+                ++computes;
+                d = cvx::Mat(3, 32, cvx::Mat::U8);
+            }
+            void detectAndCompute(const cvx::Mat&, const cvx::Mat&, std::vector<cvx::KeyPoint>& k, cvx::Mat& d) override {
+                ++both;
+                k.resize(5);
+                d = cvx::Mat(5, 32, cvx::Mat::U8);
+            }
+        };
+        auto one = std::make_shared<Counting>(), two = std::make_shared<Counting>();
+        cvx::Mat img(16, 16, cvx::Mat::U8), desc;
+        std::vector<cvx::KeyPoint> kp;
+        sfm_hip::FeatureDetector same("ORB", one, one), split("FAST", one, two), none("AKAZE");
+        same.generateFeatures(img, kp, desc);
+        if (one->both != 1 || one->detects != 0 || kp.size() != 5 || desc.rows != 5) { std::printf("detectAndCompute path wrong\n"); ++bad; }
+        split.generateFeatures(img, kp, desc);
+        if (one->detects != 1 || two->computes != 1 || two->both != 0 || desc.rows != 3) { std::printf("detect + compute path wrong\n"); ++bad; }
+        if (same.detector != one || split.extractor != two) { std::printf("public handles wrong\n"); ++bad; }
+        bad += must_raise("generateFeatures without a detector", [&] { none.generateFeatures(img, kp, desc); });
+    }
     sfm_hip::OptFlow of(cvx::TermCriteria(3, 30, 0.01), 21, 3, 10.f, 100u, 0.01f, 10.f, 30u);
     bad += must_raise("colour image into computeFlow", [&] {
         cvx::Mat c3(32, 32, cvx::Mat::U8, 3);

@@ -254,3 +254,21 @@ def test_bench_failed_rank_gives_nonzero_exit():
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_adapter_opencv_branch_compiles():
+    """The branch of include/sfm_hip_adapter.hpp that uses OpenCV's own types (and the Seam-2
+    cv::DescriptorMatcher / cv::SparsePyrLKOpticalFlow subclasses) compiles against a
+    declarations-only mirror of OpenCV's public names; every reference call site is named in
+    tests/cpp/adapter_opencv_compile.cpp.  Compile only: no OpenCV exists here to link or run."""
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only",
+                        "-I" + os.path.join(ROOT, "tests", "cpp", "opencv_decl"),
+                        "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "adapter_opencv_compile.cpp")],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-4000:]
+    # and the stand-in branch (what tests/cpp/adapter_check.cpp runs on the GPU box)
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-DSFM_ADAPTER_NO_OPENCV",
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adapter_check.cpp")],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-4000:]
