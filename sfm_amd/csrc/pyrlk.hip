@@ -21,6 +21,7 @@
 // the same order, with FP contraction disabled.
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "sfm_internal.h"
 
@@ -362,9 +363,9 @@ __device__ __forceinline__ void wave_sum_wide_n(const int (&p)[N], long long (&o
     for (int i = 0; i < N; ++i) out[i] = (long long)h[2 * i + 1] * 65536 + h[2 * i];
 }
 
-// Sums over the 16 lanes of each DPP row, result in every lane of the row: two
-// quad permutes, then the half-row and full-row mirrors.
-template <int N>
+// Sums over groups of LANES (16: a DPP row, 8: half a row) adjacent lanes, result in every
+// lane of the group: two quad permutes, then the half-row and (16 only) full-row mirrors.
+template <int N, int LANES>
 __device__ __forceinline__ void row_sum_n(int (&v)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = dpp_add<0xB1, 0xF>(v[i]);   // quad_perm [1,0,3,2]
@@ -372,27 +373,37 @@ __device__ __forceinline__ void row_sum_n(int (&v)[N]) {
     for (int i = 0; i < N; ++i) v[i] = dpp_add<0x4E, 0xF>(v[i]);   // quad_perm [2,3,0,1]
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = dpp_add<0x141, 0xF>(v[i]);  // row_half_mirror
+    if (LANES == 16) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x140, 0xF>(v[i]);  // row_mirror
+        for (int i = 0; i < N; ++i) v[i] = dpp_add<0x140, 0xF>(v[i]);  // row_mirror
+    }
 }
 
-// Exact per-row sums of N int32 partials (|partial| < 2^30) as (low 16 bits, high part)
-// halves: one add in 32 bits (two lanes cannot overflow), then the halves separately.
-template <int N>
+// Exact per-group sums of N int32 partials as (low 16 bits, high part) halves.  With 16 lanes
+// the partials stay below 2^30: one add in 32 bits (two lanes cannot overflow), then the halves
+// separately.  With 8 lanes a lane holds twice as many pixels (partials up to 2^31): the
+// halves are split before any add.
+template <int N, int LANES>
 __device__ __forceinline__ void row_sum_wide_n(const int (&p)[N], int (&lo)[N], int (&hi)[N]) {
     int h[2 * N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const int v = dpp_add<0xB1, 0xF>(p[i]);
+        const int v = LANES == 16 ? dpp_add<0xB1, 0xF>(p[i]) : p[i];
         h[2 * i] = v & 0xFFFF;
         h[2 * i + 1] = v >> 16;
+    }
+    if (LANES != 16) {
+#pragma unroll
+        for (int i = 0; i < 2 * N; ++i) h[i] = dpp_add<0xB1, 0xF>(h[i]);
     }
 #pragma unroll
     for (int i = 0; i < 2 * N; ++i) h[i] = dpp_add<0x4E, 0xF>(h[i]);
 #pragma unroll
     for (int i = 0; i < 2 * N; ++i) h[i] = dpp_add<0x141, 0xF>(h[i]);
+    if (LANES == 16) {
 #pragma unroll
-    for (int i = 0; i < 2 * N; ++i) h[i] = dpp_add<0x140, 0xF>(h[i]);
+        for (int i = 0; i < 2 * N; ++i) h[i] = dpp_add<0x140, 0xF>(h[i]);
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         lo[i] = h[2 * i];
@@ -482,8 +493,35 @@ struct SlotWin {
     uint32_t x01, x23, x45;  // interpolated dI/dx (0 outside the window)
     uint32_t y01, y23, y45;  // interpolated dI/dy
     int i6, x6, y6;
-    uint32_t m01, m23, m45;  // 0xFFFF per pixel inside the window
+};
+
+// Which of a slot's 7 pixels lie inside the window: 0xFFFF per pixel.  FULL (the window width
+// is a multiple of 7, e.g. 21): a slot is inside as a whole or not at all, and its mask is
+// rebuilt from one comparison where it is needed instead of living in four registers.
+template <bool FULL>
+struct SlotMask;
+template <>
+struct SlotMask<false> {
+    uint32_t m01, m23, m45;
     int m6;
+    __device__ __forceinline__ void set(int npx) {
+        m01 = (npx > 0 ? 0xFFFFu : 0u) | (npx > 1 ? 0xFFFF0000u : 0u);
+        m23 = (npx > 2 ? 0xFFFFu : 0u) | (npx > 3 ? 0xFFFF0000u : 0u);
+        m45 = (npx > 4 ? 0xFFFFu : 0u) | (npx > 5 ? 0xFFFF0000u : 0u);
+        m6 = npx > 6 ? -1 : 0;
+    }
+    __device__ __forceinline__ uint32_t p01(bool) const { return m01; }
+    __device__ __forceinline__ uint32_t p23(bool) const { return m23; }
+    __device__ __forceinline__ uint32_t p45(bool) const { return m45; }
+    __device__ __forceinline__ int p6(bool) const { return m6; }
+};
+template <>
+struct SlotMask<true> {
+    __device__ __forceinline__ void set(int) {}
+    __device__ __forceinline__ uint32_t p01(bool valid) const { return valid ? 0xFFFFFFFFu : 0u; }
+    __device__ __forceinline__ uint32_t p23(bool valid) const { return valid ? 0xFFFFFFFFu : 0u; }
+    __device__ __forceinline__ uint32_t p45(bool valid) const { return valid ? 0xFFFFFFFFu : 0u; }
+    __device__ __forceinline__ int p6(bool valid) const { return valid ? -1 : 0; }
 };
 
 // ((s0 >> 9) | (s1 >> 9) << 16) for two footprint sums in [1, 2^23): bytes 1..2 of each
@@ -515,7 +553,7 @@ __device__ __forceinline__ void window_interp(const uint8_t* base, unsigned o, i
 
 // LPP = lanes per point: 64 (one point per wave) or 16 (four points per wave, one per
 // DPP row; the per-point scalar work is then shared by four points per instruction).
-template <int LPP, int SPL>
+template <int LPP, int SPL, bool FULL>
 __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
     const int lane = threadIdx.x & (LPP - 1);
     // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); give each XCD one
@@ -538,21 +576,18 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
     const uint8_t* pyrJ = a.pyr_curr + (size_t)pair * g.block;
     const uint32_t* pyrD = a.deriv + (size_t)pair * g.block;
 
-    // slot geometry of this lane
-    int srow[SPL], sx0[SPL];
+    // slot geometry of this lane: (window row << 8 | first window column) per slot
+    int sgeom[SPL];
     SlotWin win[SPL];
+    SlotMask<FULL> msk[SPL];
 #pragma unroll
     for (int s = 0; s < SPL; ++s) {
         const int slot = lane + LPP * s;
         const bool valid = slot < a.slots;
         const int sl = valid ? slot : 0;
-        srow[s] = sl / a.segs;
-        sx0[s] = (sl % a.segs) * kPxPerSlot;
-        const int npx = valid ? min(kPxPerSlot, a.win_w - sx0[s]) : 0;
-        win[s].m01 = (npx > 0 ? 0xFFFFu : 0u) | (npx > 1 ? 0xFFFF0000u : 0u);
-        win[s].m23 = (npx > 2 ? 0xFFFFu : 0u) | (npx > 3 ? 0xFFFF0000u : 0u);
-        win[s].m45 = (npx > 4 ? 0xFFFFu : 0u) | (npx > 5 ? 0xFFFF0000u : 0u);
-        win[s].m6 = npx > 6 ? -1 : 0;
+        const int srow = sl / a.segs, sx0 = (sl % a.segs) * kPxPerSlot;
+        sgeom[s] = (srow << 8) | sx0;
+        msk[s].set(valid ? min(kPxPerSlot, a.win_w - sx0) : 0);
     }
 
     const float2 p0 = a.prev_pts[pt];
@@ -596,21 +631,31 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
         // offset of each slot inside a window at this level's row pitch
         unsigned soff[SPL];
 #pragma unroll
-        for (int s = 0; s < SPL; ++s) soff[s] = (unsigned)(srow[s] * S + sx0[s]);
+        for (int s = 0; s < SPL; ++s) soff[s] = (unsigned)((sgeom[s] >> 8) * S + (sgeom[s] & 0xFF));
 
         int pA[3] = {0, 0, 0};
         const unsigned obase = (unsigned)((ipy + g.bh) * S + ipx + g.bw);
 #pragma unroll
         for (int s = 0; s < SPL; ++s) {
             SlotWin& w = win[s];
+            const bool valid = lane + LPP * s < a.slots;
+            const uint32_t m01 = msk[s].p01(valid), m23 = msk[s].p23(valid), m45 = msk[s].p45(valid);
+            const int m6 = msk[s].p6(valid);
             const unsigned o = obase + soff[s];
             uint32_t i01, i23, i45;
             int i6;
             window_interp(I, o, S, wt, i01, i23, i45, i6);
-            w.i01 = i01 & w.m01;
-            w.i23 = i23 & w.m23;
-            w.i45 = i45 & w.m45;
-            w.i6 = i6 & w.m6;
+            if (FULL) {  // a slot outside the window contributes through its zero derivatives only
+                w.i01 = i01;
+                w.i23 = i23;
+                w.i45 = i45;
+                w.i6 = i6;
+            } else {
+                w.i01 = i01 & m01;
+                w.i23 = i23 & m23;
+                w.i45 = i45 & m45;
+                w.i6 = i6 & m6;
+            }
             uint32_t d0[8], d1[8];
             __builtin_memcpy(d0, D + o, 32);
             __builtin_memcpy(d1, D + (o + (unsigned)S), 32);
@@ -627,14 +672,14 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
                 ix[j] = footprint(xp[j], xp[j + 1], wt, 1 << (W_BITS - 1)) >> W_BITS;
                 iy[j] = footprint(yp[j], yp[j + 1], wt, 1 << (W_BITS - 1)) >> W_BITS;
             }
-            w.x01 = pack16(ix[0], ix[1]) & w.m01;
-            w.x23 = pack16(ix[2], ix[3]) & w.m23;
-            w.x45 = pack16(ix[4], ix[5]) & w.m45;
-            w.x6 = ix[6] & w.m6;
-            w.y01 = pack16(iy[0], iy[1]) & w.m01;
-            w.y23 = pack16(iy[2], iy[3]) & w.m23;
-            w.y45 = pack16(iy[4], iy[5]) & w.m45;
-            w.y6 = iy[6] & w.m6;
+            w.x01 = pack16(ix[0], ix[1]) & m01;
+            w.x23 = pack16(ix[2], ix[3]) & m23;
+            w.x45 = pack16(ix[4], ix[5]) & m45;
+            w.x6 = ix[6] & m6;
+            w.y01 = pack16(iy[0], iy[1]) & m01;
+            w.y23 = pack16(iy[2], iy[3]) & m23;
+            w.y45 = pack16(iy[4], iy[5]) & m45;
+            w.y6 = iy[6] & m6;
             pA[0] = mad24(w.x6, w.x6, sdot2(w.x45, w.x45, sdot2(w.x23, w.x23, sdot2(w.x01, w.x01, pA[0]))));
             pA[1] = mad24(w.x6, w.y6, sdot2(w.x45, w.y45, sdot2(w.x23, w.y23, sdot2(w.x01, w.y01, pA[1]))));
             pA[2] = mad24(w.y6, w.y6, sdot2(w.y45, w.y45, sdot2(w.y23, w.y23, sdot2(w.y01, w.y01, pA[2]))));
@@ -648,7 +693,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
             A22 = (float)sA[2] * FLT_SCALE;
         } else {
             int lo[3], hi[3];
-            row_sum_wide_n<3>(pA, lo, hi);
+            row_sum_wide_n<3, LPP>(pA, lo, hi);
             A11 = halves_to_float(hi[0], lo[0]) * FLT_SCALE;
             A12 = halves_to_float(hi[1], lo[1]) * FLT_SCALE;
             A22 = halves_to_float(hi[2], lo[2]) * FLT_SCALE;
@@ -698,7 +743,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
                 b2 = (float)sb[1] * FLT_SCALE;
             } else {
                 int lo[2], hi[2];
-                row_sum_wide_n<2>(pb, lo, hi);
+                row_sum_wide_n<2, LPP>(pb, lo, hi);
                 b1 = halves_to_float(hi[0], lo[0]) * FLT_SCALE;
                 b2 = halves_to_float(hi[1], lo[1]) * FLT_SCALE;
             }
@@ -730,25 +775,28 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) {
                     const SlotWin& w = win[s];
+                    const bool valid = lane + LPP * s < a.slots;
+                    const uint32_t m01 = msk[s].p01(valid), m23 = msk[s].p23(valid), m45 = msk[s].p45(valid);
+                    const int m6 = msk[s].p6(valid);
                     const unsigned o = ebase + soff[s];
                     uint32_t j01, j23, j45;
                     int j6;
                     window_interp(J, o, S, wt, j01, j23, j45, j6);
-                    const uint32_t dd[3] = {pk_sub_i16(j01, w.i01) & w.m01, pk_sub_i16(j23, w.i23) & w.m23,
-                                            pk_sub_i16(j45, w.i45) & w.m45};
+                    const uint32_t dd[3] = {pk_sub_i16(j01, w.i01) & m01, pk_sub_i16(j23, w.i23) & m23,
+                                            pk_sub_i16(j45, w.i45) & m45};
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const int lo = (int)(short)(dd[k] & 0xFFFF), hi = (int)dd[k] >> 16;
                         perr[0] += abs(lo) + abs(hi);
                     }
-                    perr[0] += abs((j6 - w.i6) & w.m6);
+                    perr[0] += abs((j6 - w.i6) & m6);
                 }
                 // Sum of |diff| stays below 2^24 for windows up to 41x41, so the float
                 // accumulation of the reference is exact and equals this integer sum.
                 if (LPP == 64)
                     wave_sum_n<1>(perr);
                 else
-                    row_sum_n<1>(perr);
+                    row_sum_n<1, LPP>(perr);
                 const float errval = (float)perr[0];
                 err = errval * 1.f / (float)(32 * a.win_w * a.win_h);
             }
@@ -997,25 +1045,43 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     a.status = d_status;
     a.err = d_err;
     KernelTimer timer(ctx, KID_LK_TRACK);
-    if (a.slots <= 64) {
+    static const bool eight_lanes = [] {   // measurement aid: eight lanes per point
+        const char* e = getenv("SFM_LK_LANES");
+        return e && atoi(e) == 8;
+    }();
+    if (a.slots <= 64 && a.slots > 56 && eight_lanes && win_w % kPxPerSlot == 0) {
+        const long waves = (long)n_pairs * ((n + 7) / 8);
+        const dim3 grid((unsigned)((((waves + 3) / 4 + 7) / 8) * 8));
+        hipLaunchKernelGGL((lk_track_kernel<8, 8, true>), grid, blk, 0, ctx->stream, a);
+    } else if (a.slots <= 64) {
         // four points per wave, 16 lanes each
         // four waves per workgroup, four points per wave; a multiple of 8 workgroups (see the kernel)
         const long waves = (long)n_pairs * ((n + 3) / 4);
         const dim3 grid((unsigned)((((waves + 3) / 4 + 7) / 8) * 8));
+        const bool full = win_w % kPxPerSlot == 0;
+#define SFM_LK_LAUNCH(LPP_, SPL_)                                                                     \
+    do {                                                                                              \
+        if (full)                                                                                     \
+            hipLaunchKernelGGL((lk_track_kernel<LPP_, SPL_, true>), grid, blk, 0, ctx->stream, a);    \
+        else                                                                                          \
+            hipLaunchKernelGGL((lk_track_kernel<LPP_, SPL_, false>), grid, blk, 0, ctx->stream, a);   \
+    } while (0)
         switch ((a.slots + 15) / 16) {
-            case 1: hipLaunchKernelGGL((lk_track_kernel<16, 1>), grid, blk, 0, ctx->stream, a); break;
-            case 2: hipLaunchKernelGGL((lk_track_kernel<16, 2>), grid, blk, 0, ctx->stream, a); break;
-            case 3: hipLaunchKernelGGL((lk_track_kernel<16, 3>), grid, blk, 0, ctx->stream, a); break;
-            default: hipLaunchKernelGGL((lk_track_kernel<16, 4>), grid, blk, 0, ctx->stream, a); break;
+            case 1: SFM_LK_LAUNCH(16, 1); break;
+            case 2: SFM_LK_LAUNCH(16, 2); break;
+            case 3: SFM_LK_LAUNCH(16, 3); break;
+            default: SFM_LK_LAUNCH(16, 4); break;
         }
     } else {
         const long waves = (long)n_pairs * n;  // one point per wave
         const dim3 grid((unsigned)((((waves + 3) / 4 + 7) / 8) * 8));
+        const bool full = win_w % kPxPerSlot == 0;
         switch ((a.slots + 63) / 64) {
-            case 2: hipLaunchKernelGGL((lk_track_kernel<64, 2>), grid, blk, 0, ctx->stream, a); break;
-            case 3: hipLaunchKernelGGL((lk_track_kernel<64, 3>), grid, blk, 0, ctx->stream, a); break;
-            default: hipLaunchKernelGGL((lk_track_kernel<64, 4>), grid, blk, 0, ctx->stream, a); break;
+            case 2: SFM_LK_LAUNCH(64, 2); break;
+            case 3: SFM_LK_LAUNCH(64, 3); break;
+            default: SFM_LK_LAUNCH(64, 4); break;
         }
+#undef SFM_LK_LAUNCH
     }
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;

@@ -8,8 +8,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_sq_$WL
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 150 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
-    --output-format csv -d "$OUT" -o $WL -- python3 $ROOT/bench.py --no-cpu-baseline --workload $WL --steps 2 --warmup 1 "$@" > "$OUT/run.log" 2>&1
+timeout -s KILL 150 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
+    --output-format csv -d "$OUT" -o $WL -- python3 $ROOT/bench.py --no-cpu-baseline --no-other-configs --sustain 0 --one-stream --workload $WL --steps 2 --warmup 1 "$@" > "$OUT/run.log" 2>&1
 echo rc=$?
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, re, collections
@@ -31,8 +31,8 @@ for k, c in acc.items():
     v = {n: a[0] / a[1] for n, a in c.items()}
     w = v.get("SQ_WAVES", 0) or 1
     us = dur[k][0] / dur[k][1] / 1e3
-    print(f"{k}: disp={dur[k][1]} dur={us:.1f}us waves={w:.0f} valu/wave={v.get('SQ_INSTS_VALU',0)/w:.0f} salu/wave={v.get('SQ_INSTS_SALU',0)/w:.0f} "
-          f"lds/wave={v.get('SQ_INSTS_LDS',0)/w:.0f} wave_cycles/wave={v.get('SQ_WAVE_CYCLES',0)/w:.0f} active_valu/wave={v.get('SQ_ACTIVE_INST_VALU',0)/w:.0f} "
+    print(f"{k}: disp={dur[k][1]} dur={us:.1f}us waves={w:.0f} valu/wave={v.get('SQ_INSTS_VALU',0)/w:.0f} wait_any/wave={v.get('SQ_WAIT_ANY',0)/w:.0f} "
+          f"active_any/wave={v.get('SQ_ACTIVE_INST_ANY',0)/w:.0f} wave_cycles/wave={v.get('SQ_WAVE_CYCLES',0)/w:.0f} active_valu/wave={v.get('SQ_ACTIVE_INST_VALU',0)/w:.0f} "
           f"wait_inst_any/wave={v.get('SQ_WAIT_INST_ANY',0)/w:.0f} busy_cycles={v.get('SQ_BUSY_CYCLES',0):.0f} gui_active={v.get('GRBM_GUI_ACTIVE',0):.0f} "
           f"clock_GHz~{v.get('GRBM_GUI_ACTIVE',0)/ (us*1e3) if us else 0:.2f}")
 PY
