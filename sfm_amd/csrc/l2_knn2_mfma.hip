@@ -77,6 +77,18 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
         (__attribute__((address_space(3))) void*)lptr, 16, 0, 0);
 }
 
+// mask ? a : b per lane, as one v_cndmask_b32
+__device__ __forceinline__ float select_f(unsigned long long mask, float a, float b) {
+    float r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ int select_i(unsigned long long mask, int a, int b) {
+    int r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+
 template <int K, int NT>
 __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
     constexpr int kChunksPerRow = K / 4;             // 16-byte chunks
@@ -181,6 +193,23 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
     // Keeps the two smallest keys per lane and query tile.  Candidates arrive in ascending
     // train index and comparisons are strict, so equal keys keep the lower index first; a
     // key that displaces the best pushes the old best (not the old second) down.
+    auto fold_key = [&](const floatx16 (&acc)[2][NT], int tbase, int kq) {
+        const int gi = kq / 4, r = kq % 4;
+        const int mt = gi / (NT * 4), n = (gi / 4) % NT, gq = gi % 4;
+        const float key = acc[mt][n][4 * gq + r];
+        const int ti = tbase + 32 * mt + 8 * gq + 4 * lh + r;
+        // selects written as v_cndmask on lane masks: from C++ selects the compiler builds
+        // exec-masked moves behind branches, which stall a wave that has MFMAs to issue
+        const unsigned long long c0 = __builtin_amdgcn_ballot_w64(key < best0[n]);
+        const unsigned long long c1 = __builtin_amdgcn_ballot_w64(key < best1[n]);
+        asm("v_med3_f32 %0, %0, %1, %2" : "+v"(third[n]) : "v"(key), "v"(best1[n]));
+        const float t = select_f(c1, key, best1[n]);
+        const int tix = select_i(c1, ti, bidx1[n]);
+        best1[n] = select_f(c0, best0[n], t);
+        bidx1[n] = select_i(c0, bidx0[n], tix);
+        best0[n] = select_f(c0, key, best0[n]);
+        bidx0[n] = select_i(c0, ti, bidx0[n]);
+    };
     auto fold_group = [&](const floatx16 (&acc)[2][NT], int tbase, int gi) {
         const int mt = gi / (NT * 4), n = (gi / 4) % NT, gq = gi % 4;
 #pragma unroll
@@ -230,6 +259,12 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
         };
         floatx4 av[2], av_next[2];
         load_av(0, av);
+        // One key of the finished tile is folded after every kMfmaPerKey-th MFMA, and the
+        // order is pinned: left to itself the compiler issues the MFMAs of an m step back to
+        // back and the fold after them, and a wave stuck at the head of that MFMA queue
+        // issues nothing else, so the fold then runs with the matrix pipe idle.
+        constexpr int kMfmaPerKey = (kMSteps * 4 * 2 * NT) / (kGroups * 4);
+        static_assert(kMfmaPerKey >= 1 && (kMSteps * 4 * 2 * NT) % (kGroups * 4) == 0, "whole MFMAs per key");
 #pragma unroll
         for (int m = 0; m < kMSteps; ++m) {
             if (m + 1 < kMSteps) load_av(m + 1, av_next);
@@ -238,12 +273,13 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int n = 0; n < NT; ++n)
+                    for (int n = 0; n < NT; ++n) {
                         accC[mt][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][s], qreg[n][m][s],
                                                                            accC[mt][n], 0, 0, 0);
-#pragma unroll
-            for (int gi = (m * kGroups) / kMSteps; gi < ((m + 1) * kGroups) / kMSteps; ++gi)
-                fold_group(accF, tbase_prev, gi);
+                        const int unit = ((m * 4 + s) * 2 + mt) * NT + n;
+                        if (unit % kMfmaPerKey == 0) fold_key(accF, tbase_prev, unit / kMfmaPerKey);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
             av[0] = av_next[0];
             av[1] = av_next[1];
         }
