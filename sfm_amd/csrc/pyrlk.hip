@@ -7,7 +7,7 @@
 //   - pyramid: pyrDown ([1 4 6 4 1] separable, (v+128)>>8, reflect-101), every
 //     level stored with a reflect-101 border of one window;
 //   - Scharr derivative of the previous image per level, stored as one 32-bit
-//     word per pixel (Ix in the low half, Iy in the high half), zero outside;
+//     word per pixel (4 Ix in the low half, 4 Iy in the high half), zero outside;
 //   - tracker: one 64-lane wave per point walks the levels from the top.  A lane
 //     owns up to 7 horizontally adjacent window pixels of one window row
 //     ("slot"); the window of I and of its derivatives is interpolated once per
@@ -267,7 +267,9 @@ __global__ void lk_scharr_kernel(LkGeom g, const uint8_t* __restrict__ pyr_prev,
                 const int ix = sv[j + 2] - sv[j];
                 const int iy = (dv[j + 2] + dv[j]) * 3 + dv[j + 1] * 10;
                 const bool in = (unsigned)(x0 + j) < (unsigned)w;
-                out[i] = in ? (((uint32_t)ix & 0xFFFFu) | ((uint32_t)iy << 16)) : 0u;
+                // stored times four (|4 d| <= 16320 fits 16 bits): the tracker's CV_DESCALE(.., 14)
+                // of an interpolated derivative is then the high half of the weighted sum
+                out[i] = in ? (((uint32_t)(4 * ix) & 0xFFFFu) | ((uint32_t)(4 * iy) << 16)) : 0u;
             }
             *reinterpret_cast<uint4*>(drow + xi + 4 * q) = make_uint4(out[0], out[1], out[2], out[3]);
         }
@@ -476,6 +478,11 @@ __device__ __forceinline__ uint32_t pack16(int a, int b) {
     return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x05040100u);
 }
 
+// (hi16(a) | hi16(b) << 16): the high halves of two 32-bit values side by side
+__device__ __forceinline__ uint32_t pack_hi16(int a, int b) {
+    return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x07060302u);
+}
+
 __device__ __forceinline__ int mad24(int a, int b, int c) {
     int d;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -666,20 +673,23 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
                 xp[j] = __builtin_amdgcn_perm(d1[j], d0[j], 0x05040100u);
                 yp[j] = __builtin_amdgcn_perm(d1[j], d0[j], 0x07060302u);
             }
-            int ix[kPxPerSlot], iy[kPxPerSlot];
+            // CV_DESCALE(sum, W_BITS) of the interpolated derivatives: the stored values are four
+            // times the derivatives, so (4 sum + 2^15) >> 16 is the same number and sits in the
+            // high half of the 32-bit sum, where the byte shuffle that pairs two pixels finds it
+            int sx[kPxPerSlot], sy[kPxPerSlot];
 #pragma unroll
             for (int j = 0; j < kPxPerSlot; ++j) {
-                ix[j] = footprint(xp[j], xp[j + 1], wt, 1 << (W_BITS - 1)) >> W_BITS;
-                iy[j] = footprint(yp[j], yp[j + 1], wt, 1 << (W_BITS - 1)) >> W_BITS;
+                sx[j] = footprint(xp[j], xp[j + 1], wt, 1 << (W_BITS + 1));
+                sy[j] = footprint(yp[j], yp[j + 1], wt, 1 << (W_BITS + 1));
             }
-            w.x01 = pack16(ix[0], ix[1]) & m01;
-            w.x23 = pack16(ix[2], ix[3]) & m23;
-            w.x45 = pack16(ix[4], ix[5]) & m45;
-            w.x6 = ix[6] & m6;
-            w.y01 = pack16(iy[0], iy[1]) & m01;
-            w.y23 = pack16(iy[2], iy[3]) & m23;
-            w.y45 = pack16(iy[4], iy[5]) & m45;
-            w.y6 = iy[6] & m6;
+            w.x01 = pack_hi16(sx[0], sx[1]) & m01;
+            w.x23 = pack_hi16(sx[2], sx[3]) & m23;
+            w.x45 = pack_hi16(sx[4], sx[5]) & m45;
+            w.x6 = (sx[6] >> 16) & m6;
+            w.y01 = pack_hi16(sy[0], sy[1]) & m01;
+            w.y23 = pack_hi16(sy[2], sy[3]) & m23;
+            w.y45 = pack_hi16(sy[4], sy[5]) & m45;
+            w.y6 = (sy[6] >> 16) & m6;
             pA[0] = mad24(w.x6, w.x6, sdot2(w.x45, w.x45, sdot2(w.x23, w.x23, sdot2(w.x01, w.x01, pA[0]))));
             pA[1] = mad24(w.x6, w.y6, sdot2(w.x45, w.y45, sdot2(w.x23, w.y23, sdot2(w.x01, w.y01, pA[1]))));
             pA[2] = mad24(w.y6, w.y6, sdot2(w.y45, w.y45, sdot2(w.y23, w.y23, sdot2(w.y01, w.y01, pA[2]))));
