@@ -26,6 +26,8 @@ for wl in framepair c3 c4 f1 f2 f3 vo; do
     run stats_$wl 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -o $wl \
         -- $BENCH --workload $wl --steps 5 --warmup 2
 done
+run stats_c5 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c5" -o c5 \
+    -- $BENCH --workload c5 --frames 96 --steps 3 --warmup 1
 for wl in framepair c3 c4; do
     for ctr in FETCH_SIZE WRITE_SIZE; do
         run pmc_${wl}_$ctr 120 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/pmc_${wl}_$ctr" -o $wl \

@@ -31,7 +31,7 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for wl in ("framepair", "c3", "c4", "f1", "f2", "f3", "vo"):
+    for wl in ("framepair", "c3", "c4", "c5", "f1", "f2", "f3", "vo"):
         hits = glob.glob(os.path.join(src, f"stats_{wl}", "**", "*kernel_stats.csv"), recursive=True)
         if hits:
             shutil.copy(hits[0], os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"))
