@@ -266,9 +266,36 @@ def test_match_pairs_ragged(ctx, oracle, monkeypatch, d, rows, counts, path):
     assert total > 200
 
 
+@pytest.mark.parametrize("d,kernel", [(61, "hamming_mfma_kernel"), (32, "hamming_mfma_kernel"),
+                                      (128, None)])
+def test_row_width_picks_the_kernel(ctx, oracle, d, kernel):
+    """AKAZE's 61-byte rows are zero-padded to 64 and go through the matrix-core kernel like 32-
+    and 64-byte rows; widths it has no shape for (128) must not.  The per-kernel launch
+    counters of the context say which kernel ran; the result is checked as well."""
+    from sfm_amd import capi
+
+    rng = np.random.default_rng(61 + d)
+    a, b = make_frames(rng, 700, d)
+    b = b[:650]
+    ctx.set_profiling(True)
+    before = ctx.profile()
+    got = ctx.robust_matches(capi.NORM_HAMMING, a, b, 0.8)
+    after = ctx.profile()
+    ctx.set_profiling(False)
+    ran = {k for k, (_, n) in after.items() if n > before.get(k, (0, 0))[1]}
+    if kernel:
+        assert kernel in ran, ran
+    else:
+        assert "hamming_mfma_kernel" not in ran, ran
+    want = oracle.robust_matches(oracle.NORM_HAMMING, a, b, 0.8)
+    assert len(want) > 100 and _tuples(got) == _tuples(want)
+
+
 def test_two_direction_path_agrees(oracle):
     """SFM_PAIR_KERNEL=0 routes pair matching through the single-direction kernel twice; it
-    must give what the one-pass pair kernel gives.  The switch is read once per process."""
+    must give what the default path gives.  The library reads the switch on every call; the
+    child process is only there so that the variable is set before the library loads and
+    nothing else in this test process sees it."""
     import os
     import subprocess
     import sys
