@@ -129,49 +129,71 @@ __device__ __forceinline__ uint32_t pyr_down_px(const uint8_t* src, int SS, int 
     return (uint32_t)((acc + 128) >> 8);
 }
 
-// Four horizontally adjacent pyrDown outputs (x .. x+3, row ry, all inside the level) as
-// packed bytes.  Output i takes the five source bytes 2i .. 2i+4 of a row with weights
-// 1 4 6 4 1: a byte dot product over four of them plus a second one that picks the fifth.
-// kAligned: x is a multiple of 4 (groups inside the image); mirrored border groups are not.
+// Horizontal [1 4 6 4 1] sums of one source row for four adjacent pyrDown outputs x .. x+3
+// (all inside the level): output i takes the five source bytes 2i .. 2i+4: a byte dot product
+// over four of them plus a second one that picks the fifth.  s points at source column 2x-4
+// of the row.  kAligned: x is a multiple of 4 (groups inside the image); the mirrored groups
+// of the border are not.
 template <bool kAligned>
-__device__ __forceinline__ uint32_t pyr_down_quad(const uint8_t* src, int SS, int x, int ry) {
+__device__ __forceinline__ void pyr_down_row(const uint8_t* s, uint32_t (&hs)[4]) {
     constexpr uint32_t kW = 0x04060401u;                      // weights of bytes 0..3
     constexpr uint32_t kE0 = 0x00000001u, kE2 = 0x00010000u;  // byte 0 / byte 2 alone
-    uint32_t col[4] = {128u, 128u, 128u, 128u};               // rounding of the final >> 8
-    // source columns 2x-2 .. 2x+8 of rows 2ry-2 .. 2ry+2, read as four aligned dwords from
-    // column 2x-4 (x is a multiple of 4 and rows are 16-byte aligned; a load at 2x-2 would be
-    // a misaligned one)
-    const uint8_t* s = src + (ptrdiff_t)(2 * ry - 2) * SS + (2 * x - 4);
+    // source columns 2x-2 .. 2x+8, read as four dwords from column 2x-4 (with x a multiple
+    // of 4 and rows 16-byte aligned that is one aligned load; one at 2x-2 would not be)
+    uint4 d;
+    if (kAligned)
+        d = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(s, 4));
+    else
+        __builtin_memcpy(&d, s, 16);
+    const uint32_t q0 = __builtin_amdgcn_alignbyte(d.y, d.x, 2);  // columns 2x-2 .. 2x+1
+    const uint32_t q1 = __builtin_amdgcn_alignbyte(d.z, d.y, 2);  // columns 2x+2 .. 2x+5
+    const uint32_t q2 = __builtin_amdgcn_alignbyte(d.w, d.z, 2);  // columns 2x+6 .. 2x+9
+    hs[0] = __builtin_amdgcn_udot4(q0, kW, __builtin_amdgcn_udot4(q1, kE0, 0u, false), false);
+    hs[1] = __builtin_amdgcn_udot4(d.y, kW, __builtin_amdgcn_udot4(q1, kE2, 0u, false), false);
+    hs[2] = __builtin_amdgcn_udot4(q1, kW, __builtin_amdgcn_udot4(q2, kE0, 0u, false), false);
+    hs[3] = __builtin_amdgcn_udot4(d.z, kW, __builtin_amdgcn_udot4(q2, kE2, 0u, false), false);
+}
+
+constexpr int kPyrRows = 4;  // output rows per thread of lk_pyr_down_kernel
+
+// Output rows ry0 .. ry0+3 of the four adjacent outputs x .. x+3 as packed bytes: the eleven
+// source rows 2 ry0 - 2 .. 2 ry0 + 8 are summed horizontally once each and go into up to three
+// output rows.  Source rows no stored output row needs (beyond 2 (h-1) + 2) are not read.
+template <bool kAligned>
+__device__ __forceinline__ void pyr_down_block(const uint8_t* src, int SS, int x, int ry0, int h,
+                                               uint32_t (&out)[kPyrRows]) {
+    uint32_t col[kPyrRows][4];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        uint4 d;
-        if (kAligned)
-            d = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(s + (ptrdiff_t)k * SS, 4));
-        else
-            __builtin_memcpy(&d, s + (ptrdiff_t)k * SS, 16);
-        uint32_t q[3];
-        q[0] = __builtin_amdgcn_alignbyte(d.y, d.x, 2);   // columns 2x-2 .. 2x+1
-        q[1] = __builtin_amdgcn_alignbyte(d.z, d.y, 2);   // columns 2x+2 .. 2x+5
-        q[2] = __builtin_amdgcn_alignbyte(d.w, d.z, 2);   // columns 2x+6 .. 2x+9
-        const uint32_t m01 = d.y;                         // columns 2x .. 2x+3
-        const uint32_t m12 = d.z;                         // columns 2x+4 .. 2x+7
-        const uint32_t h0 = __builtin_amdgcn_udot4(q[0], kW, __builtin_amdgcn_udot4(q[1], kE0, 0u, false), false);
-        const uint32_t h1 = __builtin_amdgcn_udot4(m01, kW, __builtin_amdgcn_udot4(q[1], kE2, 0u, false), false);
-        const uint32_t h2 = __builtin_amdgcn_udot4(q[1], kW, __builtin_amdgcn_udot4(q[2], kE0, 0u, false), false);
-        const uint32_t h3 = __builtin_amdgcn_udot4(m12, kW, __builtin_amdgcn_udot4(q[2], kE2, 0u, false), false);
-        const uint32_t wk = k == 2 ? 6u : (k == 1 || k == 3) ? 4u : 1u;
-        col[0] += wk * h0;
-        col[1] += wk * h1;
-        col[2] += wk * h2;
-        col[3] += wk * h3;
+    for (int j = 0; j < kPyrRows; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) col[j][i] = 128u;  // rounding of the final >> 8
+    const uint8_t* s = src + (ptrdiff_t)(2 * ry0 - 2) * SS + (2 * x - 4);
+    const int last = 2 * (h - 1) + 2 - (2 * ry0 - 2);  // index of the last source row in use
+#pragma unroll
+    for (int r = 0; r < 2 * kPyrRows + 3; ++r) {
+        if (r > 4 && r > last) break;
+        uint32_t hs[4];
+        pyr_down_row<kAligned>(s + (ptrdiff_t)r * SS, hs);
+#pragma unroll
+        for (int j = 0; j < kPyrRows; ++j) {
+            const int k = r - 2 * j;
+            if (k < 0 || k > 4) continue;
+            const uint32_t wk = k == 2 ? 6u : (k == 1 || k == 3) ? 4u : 1u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) col[j][i] += wk * hs[i];
+        }
     }
-    return (col[0] >> 8) | ((col[1] >> 8) << 8) | ((col[2] >> 8) << 16) | ((col[3] >> 8) << 24);
+#pragma unroll
+    for (int j = 0; j < kPyrRows; ++j)
+        out[j] = (col[j][0] >> 8) | ((col[j][1] >> 8) << 8) | ((col[j][2] >> 8) << 16) | ((col[j][3] >> 8) << 24);
 }
 
 // Level l (>= 1) of both images from level l-1, including its reflect-101 border.
-// One thread writes 4 output pixels; a group inside the image shares five 16-byte source
-// loads (11 source columns x 5 rows), a group in the left or right border is the reversed
-// group of the mirrored image columns.
+// One thread computes 4 x 4 output pixels of the image (rows ry0 .. ry0+3 of one 4-pixel
+// group of the padded row) and stores each row to its own place and to the border rows that
+// mirror it; a group in the left or right border is the reversed group of the mirrored image
+// columns.  A level is taller than the window (lk_num_levels), so a border row mirrors exactly
+// one image row and every padded row is written once.
 __global__ void lk_pyr_down_kernel(LkGeom g, int level, uint8_t* __restrict__ pyr_prev,
                                    uint8_t* __restrict__ pyr_curr) {
     const int pair = blockIdx.z >> 1, which = blockIdx.z & 1;
@@ -180,99 +202,98 @@ __global__ void lk_pyr_down_kernel(LkGeom g, int level, uint8_t* __restrict__ py
     uint8_t* dst = base + g.img_off[level];
     const int SS = g.stride[level - 1];
     const int S = g.stride[level], w = g.w[level], h = g.h[level];
-    const int per_row = S / 4, total = per_row * (h + 2 * g.bh);
+    const int per_row = S / 4, total = per_row * ((h + kPyrRows - 1) / kPyrRows);
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        int yy, xg;
-        divmod_small(t, per_row, yy, xg);
-        const int y = yy - g.bh, x4 = xg * 4;
-        const int ry = reflect101(y, h);
-        uint8_t* drow = dst + (ptrdiff_t)y * S - g.bw;
+        int rg, xg;
+        divmod_small(t, per_row, rg, xg);
+        const int ry0 = rg * kPyrRows, x4 = xg * 4;
         const int x = x4 - g.bw;
         const int m = x + 4 <= 0 ? -x - 3 : 2 * (w - 1) - x - 3;  // first column of the mirrored group
-        uint32_t v = 0;
+        uint32_t v[kPyrRows];
         if (x >= 0 && x + 4 <= w) {
-            v = pyr_down_quad<true>(src, SS, x, ry);
+            pyr_down_block<true>(src, SS, x, ry0, h, v);
         } else if ((x + 4 <= 0 || (x >= w && x + 4 <= w + g.bw)) && m >= 0 && m + 4 <= w) {
-            v = __builtin_bswap32(pyr_down_quad<false>(src, SS, m, ry));
+            pyr_down_block<false>(src, SS, m, ry0, h, v);
+#pragma unroll
+            for (int j = 0; j < kPyrRows; ++j) v[j] = __builtin_bswap32(v[j]);
         } else {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int xb = x + b;
-                const uint32_t px = xb < w + g.bw ? pyr_down_px(src, SS, reflect101(xb, w), ry) : 0u;
-                v |= px << (8 * b);
+            for (int j = 0; j < kPyrRows; ++j) {
+                v[j] = 0;
+                if (ry0 + j >= h) continue;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int xb = x + b;
+                    const uint32_t px = xb < w + g.bw ? pyr_down_px(src, SS, reflect101(xb, w), ry0 + j) : 0u;
+                    v[j] |= px << (8 * b);
+                }
             }
         }
-        *reinterpret_cast<uint32_t*>(drow + x4) = v;
+        uint8_t* dcol = dst - g.bw + x4;
+#pragma unroll
+        for (int j = 0; j < kPyrRows; ++j) {
+            const int y = ry0 + j;
+            if (y >= h) break;
+            *reinterpret_cast<uint32_t*>(dcol + (ptrdiff_t)y * S) = v[j];
+            if (y >= 1 && y <= g.bh) *reinterpret_cast<uint32_t*>(dcol - (ptrdiff_t)y * S) = v[j];
+            const int yb = 2 * (h - 1) - y;  // the row below the image that mirrors y
+            if (y <= h - 2 && yb <= h - 1 + g.bh) *reinterpret_cast<uint32_t*>(dcol + (ptrdiff_t)yb * S) = v[j];
+        }
     }
 }
 
 // Scharr derivative of the previous image, all levels in one launch (blockIdx.y = level,
-// blockIdx.z = pair); zero in the border.  One thread writes sixteen adjacent pixels (four
-// 16-byte stores) from one aligned 16-byte load and its two neighbouring dwords of each of
-// the three source rows.
+// blockIdx.z = pair); zero in the border.  One thread writes four adjacent pixels as one
+// 16-byte store (a wave: 1 KiB of one row) from one unaligned 8-byte load of each of the three
+// source rows.
 __global__ void lk_scharr_kernel(LkGeom g, const uint8_t* __restrict__ pyr_prev,
                                  uint32_t* __restrict__ deriv) {
     const int level = blockIdx.y, pair = blockIdx.z;
     const uint8_t* src = pyr_prev + (size_t)pair * g.block + g.img_off[level];
     uint32_t* dst = deriv + (size_t)pair * g.block + g.img_off[level];
     const int S = g.stride[level], w = g.w[level], h = g.h[level];
-    const int per_row = S / 16, total = per_row * (h + 2 * g.bh);
+    const int per_row = S / 4, total = per_row * (h + 2 * g.bh);
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         int yy, xg;
         divmod_small(t, per_row, yy, xg);
-        const int y = yy - g.bh, xi = xg * 16;
-        const int x0 = xi - g.bw;  // image column of the first of the sixteen pixels
+        const int y = yy - g.bh, xi = xg * 4;
+        const int x0 = xi - g.bw;  // image column of the first of the four pixels
         uint32_t* drow = dst + (ptrdiff_t)y * S - g.bw;
-        if (!(y >= 0 && y < h && x0 + 15 >= 0 && x0 < w)) {
+        uint4 out = make_uint4(0, 0, 0, 0);
+        if (y >= 0 && y < h && x0 >= 0 && x0 < w) {
+            // padded columns x0-1 .. x0+4 of rows y-1, y, y+1 (lkpyramid.cpp calcSharrDeriv:
+            // vertical pass first, then the horizontal one)
+            const uint8_t* r1 = src + (ptrdiff_t)y * S + x0 - 1;
+            uint2 a, b, c;
+            __builtin_memcpy(&a, r1 - S, 8);
+            __builtin_memcpy(&b, r1, 8);
+            __builtin_memcpy(&c, r1 + S, 8);
+            int sv[6], dv[6];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<uint4*>(drow + xi + 4 * q) = make_uint4(0, 0, 0, 0);
-            continue;
-        }
-        // padded columns xi-1 .. xi+16 of rows y-1, y, y+1 (lkpyramid.cpp calcSharrDeriv:
-        // vertical pass first, then the horizontal one)
-        int sv[18], dv[18];
-        {
-            uint32_t px[3][18];
-            const uint8_t* r1 = src + (ptrdiff_t)y * S + x0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const uint8_t* row = r1 + (ptrdiff_t)(r - 1) * S;
-                const uint32_t a = xi >= 4 ? *reinterpret_cast<const uint32_t*>(row - 4) : 0u;
-                const uint4 b = *reinterpret_cast<const uint4*>(row);
-                const uint32_t c = xi + 16 < S ? *reinterpret_cast<const uint32_t*>(row + 16) : 0u;
-                px[r][0] = a >> 24;
-                const uint32_t bw[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    px[r][1 + 4 * q] = bw[q] & 0xFF;
-                    px[r][2 + 4 * q] = (bw[q] >> 8) & 0xFF;
-                    px[r][3 + 4 * q] = (bw[q] >> 16) & 0xFF;
-                    px[r][4 + 4 * q] = bw[q] >> 24;
-                }
-                px[r][17] = c & 0xFF;
+            for (int k = 0; k < 6; ++k) {
+                const int sh = 8 * (k & 3);
+                const int p0 = (int)(((k < 4 ? a.x : a.y) >> sh) & 0xFF);
+                const int p1 = (int)(((k < 4 ? b.x : b.y) >> sh) & 0xFF);
+                const int p2 = (int)(((k < 4 ? c.x : c.y) >> sh) & 0xFF);
+                sv[k] = (p0 + p2) * 3 + p1 * 10;
+                dv[k] = p2 - p0;
             }
-#pragma unroll
-            for (int k = 0; k < 18; ++k) {
-                sv[k] = (int)(px[0][k] + px[2][k]) * 3 + (int)px[1][k] * 10;
-                dv[k] = (int)px[2][k] - (int)px[0][k];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t out[4];
+            uint32_t o[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int j = 4 * q + i;
-                const int ix = sv[j + 2] - sv[j];
-                const int iy = (dv[j + 2] + dv[j]) * 3 + dv[j + 1] * 10;
-                const bool in = (unsigned)(x0 + j) < (unsigned)w;
+                const int ix = sv[i + 2] - sv[i];
+                const int iy = (dv[i + 2] + dv[i]) * 3 + dv[i + 1] * 10;
                 // stored times four (|4 d| <= 16320 fits 16 bits): the tracker's CV_DESCALE(.., 14)
                 // of an interpolated derivative is then the high half of the weighted sum
-                out[i] = in ? (((uint32_t)(4 * ix) & 0xFFFFu) | ((uint32_t)(4 * iy) << 16)) : 0u;
+                o[i] = x0 + i < w ? (((uint32_t)(4 * ix) & 0xFFFFu) | ((uint32_t)(4 * iy) << 16)) : 0u;
             }
-            *reinterpret_cast<uint4*>(drow + xi + 4 * q) = make_uint4(out[0], out[1], out[2], out[3]);
+            out = make_uint4(o[0], o[1], o[2], o[3]);
         }
+        uint32_t* dp = drow + xi;
+        __builtin_nontemporal_store(out.x, dp);
+        __builtin_nontemporal_store(out.y, dp + 1);
+        __builtin_nontemporal_store(out.z, dp + 2);
+        __builtin_nontemporal_store(out.w, dp + 3);
     }
 }
 
@@ -1022,7 +1043,7 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     }
     for (int l = 1; l <= g.levels; ++l) {
         const int S = g.stride[l];
-        const dim3 grid(((S / 4) * (g.h[l] + 2 * g.bh) + 255) / 256, 1, 2 * n_pairs);
+        const dim3 grid(((S / 4) * ((g.h[l] + kPyrRows - 1) / kPyrRows) + 255) / 256, 1, 2 * n_pairs);
         KernelTimer timer(ctx, KID_LK_PYR_DOWN);
         hipLaunchKernelGGL(lk_pyr_down_kernel, grid, blk, 0, ctx->stream, g, l, bufs.pyr_prev,
                            bufs.pyr_curr);
@@ -1030,7 +1051,9 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     }
     {
         const int S = g.stride[0];
-        const dim3 grid(((S / 16) * (g.h[0] + 2 * g.bh) + 255) / 256, g.levels + 1, n_pairs);
+        // four groups per thread at level 0: workgroups that find nothing to do at the smaller
+        // levels are then a small part of the launch
+        const dim3 grid(((S / 4) * (g.h[0] + 2 * g.bh) + 1023) / 1024, g.levels + 1, n_pairs);
         KernelTimer timer(ctx, KID_LK_SCHARR);
         hipLaunchKernelGGL(lk_scharr_kernel, grid, blk, 0, ctx->stream, g, bufs.pyr_prev, bufs.deriv);
         SFM_HIP_CHECK(ctx, hipGetLastError());
