@@ -18,6 +18,7 @@
 //   em_score_kernel   Sampson distance of every correspondence to each of the (up to ten)
 //                     matrices, inliers counted with integer atomics.
 #include <cfloat>
+#include <utility>
 #include <cmath>
 
 #include "sfm_internal.h"
@@ -121,7 +122,21 @@ constexpr Mono make_mono() {
         }
     return m;
 }
-__constant__ Mono kMono = make_mono();
+constexpr Mono kM = make_mono();  // read at compile time only: every loop over monomials is unrolled
+constexpr int mono_degree(int i) { return kM.e[i][0] + kM.e[i][1] + kM.e[i][2]; }
+// the six terms of a 3 x 3 determinant: column of rows 0, 1, 2 and the sign
+constexpr int kPerm[6][4] = {{0, 1, 2, 1}, {1, 2, 0, 1}, {2, 0, 1, 1}, {0, 2, 1, -1}, {1, 0, 2, -1}, {2, 1, 0, -1}};
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose counter is a
+// compile-time constant inside the body
+template <class F, int... I>
+__device__ __forceinline__ void unroll_seq(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void unroll(F&& f) {
+    unroll_seq(f, std::make_integer_sequence<int, N>{});
+}
 
 // The solver's work arrays live in LDS, one column per sample: element i of a sample's array
 // sits kSolveLanes doubles after element i - 1 (scratch memory made every one of the
@@ -133,21 +148,26 @@ struct Lds {
     __device__ __forceinline__ Lds at(int offset) const { return {p + offset * kSolveLanes}; }
 };
 // doubles per sample
-constexpr int kSolveQ = 45, kSolveEe = 36, kSolveLin = 36, kSolveLam = 180, kSolveA = 200, kSolveB = 39,
-              kSolvePz = 45, kSolveTmp = 60;
-constexpr int kSolveDoubles = kSolveQ + kSolveEe + kSolveLin + kSolveLam + kSolveA + kSolveB + kSolvePz + kSolveTmp;
+constexpr int kSolveQ = 45, kSolveEe = 36, kSolveLam = 180, kSolveA = 200, kSolveB = 39;
+constexpr int kSolveDoubles = kSolveQ + kSolveEe + kSolveLam + kSolveA + kSolveB;
 
-// out += scale * a * l, l a linear polynomial given by its (x, y, z, 1) coefficients
-__device__ void mul_linear_acc(Lds a, Lds l, double scale, Lds out) {
-    for (int p = 0; p < 20; ++p) {
-        const double ap = a[p];
-        if (ap == 0) continue;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int t = kMono.times[p][v];
-            if (t >= 0) out[t] += scale * ap * l[v];
+// out += scale * a * l on registers: l a linear polynomial given by its (x, y, z, 1)
+// coefficients, a a polynomial of total degree <= DEG (its other coefficients are zero by
+// construction and are skipped); NEG: scale = -1.  Terms are added monomial by monomial of a,
+// then coefficient by coefficient of l.
+template <int DEG, bool NEG>
+__device__ __forceinline__ void mul_linear_acc_reg(const double (&a)[20], const double (&l)[4], double (&out)[20]) {
+    unroll<20>([&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        if constexpr (mono_degree(P) <= DEG) {
+            const double ap = NEG ? -a[P] : a[P];
+            unroll<4>([&](auto vc) {
+                constexpr int V = decltype(vc)::value;
+                constexpr int T = kM.times[P][V];
+                if constexpr (T >= 0) out[T] += ap * l[V];
+            });
         }
-    }
+    });
 }
 
 struct Cplx {
@@ -189,7 +209,10 @@ __device__ void solve_poly_generic(const double* coeffs, int n, Cplx* roots) {
 
 // cv::solvePoly for degree 10.  OpenCV sweeps until a sweep changes nothing at all (in
 // practice all 300 times); here the sweeps stop once the corrections are rounding noise
-// (below 1e-11 relative and no longer shrinking).
+// (below 1e-11 relative and no longer shrinking).  The size of a sweep's corrections is
+// measured as max |q|^2 / (1 + |p|^2) over the roots p and their corrections q -- squares and
+// a reciprocal estimate instead of two square roots and a division per root: the quantity only
+// steers when to stop.
 // The usual case (a leading coefficient that does not vanish) keeps coefficients and roots
 // in registers: every loop over them is unrolled.
 __device__ void solve_poly10(const double* coeffs_in, Cplx* roots_out) {
@@ -214,9 +237,9 @@ __device__ void solve_poly10(const double* coeffs_in, Cplx* roots_out) {
             p = c_mul(p, r);
         }
     }
-    double prev_rel = DBL_MAX;
+    double prev_r2 = DBL_MAX;
     for (int iter = 0; iter < 300; iter++) {
-        double max_rel = 0;
+        double max_r2 = 0;
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             const Cplx p = roots[i];
@@ -225,24 +248,30 @@ __device__ void solve_poly10(const double* coeffs_in, Cplx* roots_out) {
             for (int j = 0; j < 10; j++) {
                 num = c_mul(num, p);
                 num.re += c[9 - j];
-                if (j != i) {
+                if (j != i) denom = c_mul(denom, Cplx{p.re - roots[j].re, p.im - roots[j].im});
+            }
+            // solvePoly leaves a difference that is exactly zero out of the product.  With such
+            // a factor the plain product above is exactly zero (or not a number, after an
+            // overflow): only then are the factors tested one by one.
+            if (!(fabs(denom.re) + fabs(denom.im) > 0)) {
+                denom = {c[10], 0};
+#pragma unroll
+                for (int j = 0; j < 10; j++) {
+                    if (j == i) continue;
                     const Cplx d = {p.re - roots[j].re, p.im - roots[j].im};
-                    const Cplx nd = c_mul(denom, d);
-                    const bool same = d.re == 0 && d.im == 0;
-                    denom.re = same ? denom.re : nd.re;
-                    denom.im = same ? denom.im : nd.im;
+                    if (d.re != 0 || d.im != 0) denom = c_mul(denom, d);
                 }
             }
             const double t = 1. / (denom.re * denom.re + denom.im * denom.im);
             const Cplx q = {(num.re * denom.re + num.im * denom.im) * t, (-num.re * denom.im + num.im * denom.re) * t};
             roots[i] = {p.re - q.re, p.im - q.im};
-            const double rel = sqrt(q.re * q.re + q.im * q.im) / (1.0 + sqrt(p.re * p.re + p.im * p.im));
-            max_rel = rel > max_rel ? rel : max_rel;
+            const double r2 = (q.re * q.re + q.im * q.im) * __builtin_amdgcn_rcp(1.0 + (p.re * p.re + p.im * p.im));
+            max_r2 = r2 > max_r2 ? r2 : max_r2;
         }
         // converged: the corrections are at the rounding floor of the Horner evaluation
         // (they stop shrinking once they are tiny) -- or vanish altogether
-        if (!(max_rel > 4e-16) || (max_rel < 1e-11 && max_rel > 0.25 * prev_rel)) break;
-        prev_rel = max_rel;
+        if (!(max_r2 > 1.6e-31) || (max_r2 < 1e-22 && max_r2 > 0.0625 * prev_r2)) break;
+        prev_r2 = max_r2;
     }
 #pragma unroll
     for (int i = 0; i < 10; i++) roots_out[i] = roots[i];
@@ -251,8 +280,7 @@ __device__ void solve_poly10(const double* coeffs_in, Cplx* roots_out) {
 // EMEstimatorCallback::runKernel for five normalised correspondences; up to ten matrices
 // (9 doubles each) to `ematrix`.  `work` is this sample's column of the workgroup's LDS.
 __device__ int five_point(const double2* s1, const double2* s2, Lds work, double* ematrix) {
-    const Lds q = work, ee = q.at(kSolveQ), lin = ee.at(kSolveEe), lam = lin.at(kSolveLin), a = lam.at(kSolveLam),
-              b = a.at(kSolveA), pz = b.at(kSolveB), tmp = pz.at(kSolvePz);
+    const Lds q = work, ee = q.at(kSolveQ), lam = ee.at(kSolveEe), a = lam.at(kSolveLam), b = a.at(kSolveA);
     for (int i = 0; i < 5; ++i) {
         const double x1 = s1[i].x, y1 = s1[i].y, x2 = s2[i].x, y2 = s2[i].y;
         const Lds r = q.at(9 * i);
@@ -321,108 +349,168 @@ __device__ int five_point(const double2* s1, const double2* s2, Lds work, double
             for (int j = 0; j < 9; ++j) ee[v * 9 + j] *= inv;
         }
     }
-    // entries of E as linear polynomials: lin[k * 4 + v] = (x, y, z, 1) coefficients of entry k
+    // From here to the root finder everything is straight-line code on registers with every
+    // monomial index a compile-time constant; sums are formed in the order of the loops that
+    // define them (terms whose factor is zero by construction are left out: they add nothing).
+    // entries of E as linear polynomials: lin[k][v] = (x, y, z, 1) coefficient of entry k
+    double lin[9][4];
+#pragma unroll
     for (int k = 0; k < 9; ++k)
-        for (int v = 0; v < 4; ++v) lin[k * 4 + v] = ee[v * 9 + k];
-    const Lds l1 = tmp, t20 = tmp.at(20);  // two scratch polynomials
-    // Lambda = E E^T - tr(E E^T) / 2 I, quadratic entries held as full 20-vectors
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) {
-            const Lds o = lam.at(20 * (3 * r + c));
-            for (int m = 0; m < 20; ++m) o[m] = 0;
-            for (int k = 0; k < 3; ++k) {
-                for (int m = 0; m < 20; ++m) l1[m] = 0;
-                for (int v = 0; v < 4; ++v) l1[kMono.lin[v]] = lin[(3 * r + k) * 4 + v];
-                mul_linear_acc(l1, lin.at((3 * c + k) * 4), 1.0, o);
-            }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) lin[k][v] = ee[v * 9 + k];
+    // Lambda = E E^T - tr(E E^T) / 2 I: nine quadratics, kept in LDS (lam[20 * entry + monomial])
+    unroll<9>([&](auto rc) {
+        constexpr int R = decltype(rc)::value / 3, C = decltype(rc)::value % 3;
+        double o[20] = {};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double l1[20] = {};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) l1[kM.lin[v]] = lin[3 * R + k][v];
+            mul_linear_acc_reg<1, false>(l1, lin[3 * C + k], o);
         }
-    for (int m = 0; m < 20; ++m) {
-        const double half = 0.5 * (lam[m] + lam[80 + m] + lam[160 + m]);
-        lam[m] -= half;
-        lam[80 + m] -= half;
-        lam[160 + m] -= half;
-    }
-    for (int r = 0; r < 200; ++r) a[r] = 0;
+        unroll<20>([&](auto mc) {
+            constexpr int M = decltype(mc)::value;
+            if constexpr (mono_degree(M) <= 2) lam[20 * (3 * R + C) + M] = o[M];
+        });
+    });
+    unroll<20>([&](auto mc) {
+        constexpr int M = decltype(mc)::value;
+        if constexpr (mono_degree(M) <= 2) {
+            const double half = 0.5 * (lam[M] + lam[80 + M] + lam[160 + M]);
+            lam[M] -= half;
+            lam[80 + M] -= half;
+            lam[160 + M] -= half;
+        }
+    });
+    // ten cubic equations, rows of a: det E, then the nine entries of Lambda E
     {
-        const int8_t perm[6][4] = {{0, 1, 2, 1}, {1, 2, 0, 1}, {2, 0, 1, 1}, {0, 2, 1, -1}, {1, 0, 2, -1}, {2, 1, 0, -1}};
-        for (int p = 0; p < 6; ++p) {
-            for (int m = 0; m < 20; ++m) l1[m] = t20[m] = 0;
-            for (int v = 0; v < 4; ++v) l1[kMono.lin[v]] = lin[perm[p][0] * 4 + v];
-            mul_linear_acc(l1, lin.at((3 + perm[p][1]) * 4), 1.0, t20);
-            mul_linear_acc(t20, lin.at((6 + perm[p][2]) * 4), (double)perm[p][3], a);
-        }
+        double row[20] = {};
+        unroll<6>([&](auto pc) {
+            constexpr int P = decltype(pc)::value;
+            double l1[20] = {}, t20[20] = {};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) l1[kM.lin[v]] = lin[kPerm[P][0]][v];
+            mul_linear_acc_reg<1, false>(l1, lin[3 + kPerm[P][1]], t20);
+            mul_linear_acc_reg<2, (kPerm[P][3] < 0)>(t20, lin[6 + kPerm[P][2]], row);
+        });
+#pragma unroll
+        for (int m = 0; m < 20; ++m) a[m] = row[m];
     }
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c)
-            for (int k = 0; k < 3; ++k)
-                mul_linear_acc(lam.at(20 * (3 * r + k)), lin.at((3 * k + c) * 4), 1.0, a.at(20 * (1 + 3 * r + c)));
-    // A[:, :10]^-1 A[:, 10:]
-    for (int k = 0; k < 10; ++k) {
-        int pr = k;
-        for (int r = k + 1; r < 10; ++r)
-            if (fabs(a[r * 20 + k]) > fabs(a[pr * 20 + k])) pr = r;
-        if (a[pr * 20 + k] == 0) return 0;
-        if (pr != k)
-            for (int c = 0; c < 20; ++c) {
-                const double t = a[k * 20 + c];
-                a[k * 20 + c] = a[pr * 20 + c];
-                a[pr * 20 + c] = t;
-            }
-        const double inv = 1.0 / a[k * 20 + k];
-        for (int c = 0; c < 20; ++c) a[k * 20 + c] *= inv;
+    unroll<9>([&](auto rc) {
+        constexpr int R = decltype(rc)::value / 3, C = decltype(rc)::value % 3;
+        double row[20] = {};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double lq[20] = {};
+            unroll<20>([&](auto mc) {
+                constexpr int M = decltype(mc)::value;
+                if constexpr (mono_degree(M) <= 2) lq[M] = lam[20 * (3 * R + k) + M];
+            });
+            mul_linear_acc_reg<2, false>(lq, lin[3 * k + C], row);
+        }
+#pragma unroll
+        for (int m = 0; m < 20; ++m) a[20 * (1 + 3 * R + C) + m] = row[m];
+    });
+    // A[:, :10]^-1 A[:, 10:] by Gauss-Jordan with partial pivoting.  Columns left of the pivot
+    // are already zero in the pivot row and the pivot column is not read again, so step k
+    // touches columns k+1 .. 19 only; a row with a zero multiplier is updated by zeros.
+    bool singular = false;
+    unroll<10>([&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        int pr = K;
+        double best = fabs(a[K * 20 + K]);
+#pragma unroll
+        for (int r = K + 1; r < 10; ++r) {
+            const double v = fabs(a[r * 20 + K]);
+            if (v > best) best = v, pr = r;
+        }
+        singular |= best == 0;
+        double pk[20], rk[20];
+#pragma unroll
+        for (int c = K; c < 20; ++c) {
+            pk[c] = a[pr * 20 + c];
+            rk[c] = a[K * 20 + c];
+        }
+        const double inv = 1.0 / pk[K];
+#pragma unroll
+        for (int c = K + 1; c < 20; ++c) {
+            a[pr * 20 + c] = rk[c];       // the swap (a no-op when pr == K: overwritten next)
+            pk[c] *= inv;
+        }
+        a[pr * 20 + K] = rk[K];
+#pragma unroll
+        for (int c = K + 1; c < 20; ++c) a[K * 20 + c] = pk[c];
+#pragma unroll
         for (int r = 0; r < 10; ++r) {
-            if (r == k) continue;
-            const double m = a[r * 20 + k];
-            if (m == 0) continue;
-            for (int c = 0; c < 20; ++c) a[r * 20 + c] -= m * a[k * 20 + c];
+            if (r == K) continue;
+            const double m = a[r * 20 + K];
+#pragma unroll
+            for (int c = K + 1; c < 20; ++c) a[r * 20 + c] -= m * pk[c];
         }
-    }
-    // B(z): b[i * 13 + k], columns x z^3, x z^2, x z, x | y z^3, y z^2, y z, y | z^4, z^3, z^2, z, 1
+    });
+    if (singular) return 0;
+    // B(z): bm[i][k], columns x z^3, x z^2, x z, x | y z^3, y z^2, y z, y | z^4, z^3, z^2, z, 1
+    double bm[3][13];
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const Lds r1 = a.at((4 + 2 * i) * 20 + 10);
-        const Lds r2 = a.at((5 + 2 * i) * 20 + 10);
-        const Lds row1 = tmp, row2 = tmp.at(13);
-        for (int k = 0; k < 13; ++k) row1[k] = row2[k] = 0;
+        double r1[10], r2[10], row1[13] = {}, row2[13] = {};
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            r1[k] = a[(4 + 2 * i) * 20 + 10 + k];
+            r2[k] = a[(5 + 2 * i) * 20 + 10 + k];
+        }
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
             row1[1 + k] = r1[k];
             row1[5 + k] = r1[3 + k];
             row2[k] = r2[k];
             row2[4 + k] = r2[3 + k];
         }
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
             row1[9 + k] = r1[6 + k];
             row2[8 + k] = r2[6 + k];
         }
-        for (int k = 0; k < 13; ++k) b[i * 13 + k] = row1[k] - row2[k];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) {
+            bm[i][k] = row1[k] - row2[k];
+            b[i * 13 + k] = bm[i][k];
+        }
     }
     double c[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) c[k] = 0;
     {
-        // pz[(i * 3 + j) * 5 + k]: entry (i, j) of B as a polynomial in z, lowest degree first
+        // pz[i][j][k]: entry (i, j) of B as a polynomial in z, lowest degree first
+        double pz[3][3][5];
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
-            for (int k = 0; k < 5; ++k) pz[(i * 3) * 5 + k] = pz[(i * 3 + 1) * 5 + k] = pz[(i * 3 + 2) * 5 + k] = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) pz[i][0][k] = pz[i][1][k] = pz[i][2][k] = 0;
+#pragma unroll
             for (int k = 0; k < 4; ++k) {
-                pz[(i * 3) * 5 + k] = b[i * 13 + 3 - k];
-                pz[(i * 3 + 1) * 5 + k] = b[i * 13 + 7 - k];
+                pz[i][0][k] = bm[i][3 - k];
+                pz[i][1][k] = bm[i][7 - k];
             }
-            for (int k = 0; k < 5; ++k) pz[(i * 3 + 2) * 5 + k] = b[i * 13 + 12 - k];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) pz[i][2][k] = bm[i][12 - k];
         }
-        const int8_t perm[6][4] = {{0, 1, 2, 1}, {1, 2, 0, 1}, {2, 0, 1, 1}, {0, 2, 1, -1}, {1, 0, 2, -1}, {2, 1, 0, -1}};
-        for (int p = 0; p < 6; ++p) {
+        unroll<6>([&](auto pc) {
+            constexpr int P = decltype(pc)::value;
             double t[9];
 #pragma unroll
             for (int u = 0; u < 9; ++u) t[u] = 0;
 #pragma unroll
             for (int u = 0; u < 5; ++u)
 #pragma unroll
-                for (int v = 0; v < 5; ++v) t[u + v] += pz[perm[p][0] * 5 + u] * pz[(3 + perm[p][1]) * 5 + v];
+                for (int v = 0; v < 5; ++v) t[u + v] += pz[0][kPerm[P][0]][u] * pz[1][kPerm[P][1]][v];
 #pragma unroll
             for (int u = 0; u < 9; ++u)
 #pragma unroll
                 for (int v = 0; v < 5; ++v)
-                    if (u + v <= 10) c[u + v] += perm[p][3] * t[u] * pz[(6 + perm[p][2]) * 5 + v];
-        }
+                    if (u + v <= 10) c[u + v] += kPerm[P][3] * t[u] * pz[2][kPerm[P][2]][v];
+        });
     }
     Cplx roots[10];
     solve_poly10(c, roots);

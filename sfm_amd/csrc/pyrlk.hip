@@ -684,9 +684,12 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
                 w.i45 = i45 & m45;
                 w.i6 = i6 & m6;
             }
+            // a slot outside a FULL window reads the zero border at the start of the padded level
+            // (at least 3 rows and 16 columns) instead of being masked afterwards
+            const unsigned od = FULL ? (valid ? o : 0u) : o;
             uint32_t d0[8], d1[8];
-            __builtin_memcpy(d0, D + o, 32);
-            __builtin_memcpy(d1, D + (o + (unsigned)S), 32);
+            __builtin_memcpy(d0, D + od, 32);
+            __builtin_memcpy(d1, D + (od + (unsigned)S), 32);
             // column pairs (row y, row y+1) of Ix and of Iy, then CV_DESCALE(..., W_BITS)
             uint32_t xp[8], yp[8];
 #pragma unroll
@@ -703,14 +706,24 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
                 sx[j] = footprint(xp[j], xp[j + 1], wt, 1 << (W_BITS + 1));
                 sy[j] = footprint(yp[j], yp[j + 1], wt, 1 << (W_BITS + 1));
             }
-            w.x01 = pack_hi16(sx[0], sx[1]) & m01;
-            w.x23 = pack_hi16(sx[2], sx[3]) & m23;
-            w.x45 = pack_hi16(sx[4], sx[5]) & m45;
-            w.x6 = (sx[6] >> 16) & m6;
-            w.y01 = pack_hi16(sy[0], sy[1]) & m01;
-            w.y23 = pack_hi16(sy[2], sy[3]) & m23;
-            w.y45 = pack_hi16(sy[4], sy[5]) & m45;
-            w.y6 = (sy[6] >> 16) & m6;
+            w.x01 = pack_hi16(sx[0], sx[1]);
+            w.x23 = pack_hi16(sx[2], sx[3]);
+            w.x45 = pack_hi16(sx[4], sx[5]);
+            w.x6 = sx[6] >> 16;
+            w.y01 = pack_hi16(sy[0], sy[1]);
+            w.y23 = pack_hi16(sy[2], sy[3]);
+            w.y45 = pack_hi16(sy[4], sy[5]);
+            w.y6 = sy[6] >> 16;
+            if (!FULL) {
+                w.x01 &= m01;
+                w.x23 &= m23;
+                w.x45 &= m45;
+                w.x6 &= m6;
+                w.y01 &= m01;
+                w.y23 &= m23;
+                w.y45 &= m45;
+                w.y6 &= m6;
+            }
             pA[0] = mad24(w.x6, w.x6, sdot2(w.x45, w.x45, sdot2(w.x23, w.x23, sdot2(w.x01, w.x01, pA[0]))));
             pA[1] = mad24(w.x6, w.y6, sdot2(w.x45, w.y45, sdot2(w.x23, w.y23, sdot2(w.x01, w.y01, pA[1]))));
             pA[2] = mad24(w.y6, w.y6, sdot2(w.y45, w.y45, sdot2(w.y23, w.y23, sdot2(w.y01, w.y01, pA[2]))));

@@ -63,6 +63,8 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned* out, unsigned seed)
                 if (OP == 36) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "v"(seed));
                 if (OP == 37) asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "v"(seed));
                 if (OP == 38) asm volatile("v_sad_u8 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "v"(seed));
+                if (OP == 65) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(fk), "v"(f[(i + 1) & 7]));
+                if (OP == 66) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(f[i]) : "v"(fk));
                 if (OP == 39) asm volatile("v_min_f32 %0, %0, %1" : "+v"(f[i]) : "v"(fk));
                 if (OP == 40) asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[i]) : "v"(fk));
                 if (OP == 41) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(fk), "v"(f[(i + 1) & 7]));
@@ -181,6 +183,8 @@ int main(int argc, char**) {
     CHECK(hipMalloc(&d_out, 64));
     const bool extra_only = argc > 1;
     for (int w : {2, 4, 8}) {
+        run<65>("v_min3_f32", w, d_out);
+        run<66>("v_pk_min_f16", w, d_out);
         run<39>("v_min_f32", w, d_out);
         run<40>("v_max_f32", w, d_out);
         run<41>("v_med3_f32", w, d_out);
