@@ -138,14 +138,15 @@ __device__ __forceinline__ void unroll(F&& f) {
     unroll_seq(f, std::make_integer_sequence<int, N>{});
 }
 
-// The solver's work arrays live in LDS, one column per sample: element i of a sample's array
-// sits kSolveLanes doubles after element i - 1 (scratch memory made every one of the
-// solver's few thousand dependent array accesses an L2 round trip).
-constexpr int kSolveLanes = 16;  // samples per workgroup
+// A workgroup is one wave and solves four samples, one per row of 16 lanes.  The solver's work
+// arrays live in LDS, one column per sample: element i of a sample's array sits kSolveRows
+// doubles after element i - 1 (scratch memory made every one of the solver's few thousand
+// dependent array accesses an L2 round trip).
+constexpr int kSolveRows = 4;  // samples per workgroup
 struct Lds {
     double* p;
-    __device__ __forceinline__ double& operator[](int i) const { return p[i * kSolveLanes]; }
-    __device__ __forceinline__ Lds at(int offset) const { return {p + offset * kSolveLanes}; }
+    __device__ __forceinline__ double& operator[](int i) const { return p[i * kSolveRows]; }
+    __device__ __forceinline__ Lds at(int offset) const { return {p + offset * kSolveRows}; }
 };
 // doubles per sample
 constexpr int kSolveQ = 45, kSolveEe = 36, kSolveLam = 180, kSolveA = 200, kSolveB = 39;
@@ -207,79 +208,129 @@ __device__ void solve_poly_generic(const double* coeffs, int n, Cplx* roots) {
     }
 }
 
-// cv::solvePoly for degree 10.  OpenCV sweeps until a sweep changes nothing at all (in
-// practice all 300 times); here the sweeps stop once the corrections are rounding noise
-// (below 1e-11 relative and no longer shrinking).  The size of a sweep's corrections is
-// measured as max |q|^2 / (1 + |p|^2) over the roots p and their corrections q -- squares and
-// a reciprocal estimate instead of two square roots and a division per root: the quantity only
-// steers when to stop.
-// The usual case (a leading coefficient that does not vanish) keeps coefficients and roots
-// in registers: every loop over them is unrolled.
-__device__ void solve_poly10(const double* coeffs_in, Cplx* roots_out) {
-    int n = 10;
-    for (; n > 1; n--)
-        if (fabs(coeffs_in[n]) > DBL_EPSILON) break;
-    if (n < 10) {
-        solve_poly_generic(coeffs_in, n, roots_out);
-        for (; n < 10; n++) roots_out[n] = roots_out[n - 1];
-        return;
+// Value of lane I of the caller's row of 16 lanes, in every lane of the row.  All 64 lanes
+// must execute it (a lane that is switched off is read as zero).
+template <int I>
+__device__ __forceinline__ double row_bcast(double x) {
+    constexpr int kPattern = (I << 5) | 0x10;  // lane = (lane & 0x10) | I within each half wave
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), kPattern);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), kPattern);
+    return __hiloint2double(hi, lo);
+}
+// max over the row, in every lane of the row
+__device__ __forceinline__ double row_max(double x) {
+#define SFM_ROW_MAX_STEP(XOR)                                                                     \
+    {                                                                                             \
+        const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), ((XOR) << 10) | 0x1F);      \
+        const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), ((XOR) << 10) | 0x1F);      \
+        const double o = __hiloint2double(hi, lo);                                                \
+        x = o > x ? o : x;                                                                        \
     }
-    double c[11];
-    Cplx roots[10];
-#pragma unroll
-    for (int k = 0; k < 11; ++k) c[k] = coeffs_in[k];
+    SFM_ROW_MAX_STEP(1)
+    SFM_ROW_MAX_STEP(2)
+    SFM_ROW_MAX_STEP(4)
+    SFM_ROW_MAX_STEP(8)
+#undef SFM_ROW_MAX_STEP
+    return x;
+}
+
+// cv::solvePoly for degree 10 with a leading coefficient that does not vanish, one polynomial
+// per row of 16 lanes: lane `sub` < 10 of a row owns root `sub` (the other lanes run along).
+// solvePoly updates the roots one after the other inside a sweep, each from the roots already
+// updated; that order is kept: the ten Horner evaluations of a sweep (each needs only its own
+// root) run side by side, and the product of differences of root i takes the factors of roots
+// 0 .. i-1 one by one as these are finished, then, alone, the factors of the roots after it.
+// Every root sees the same operations in the same order as in the sequential loop.
+// OpenCV sweeps until a sweep changes nothing at all (in practice all 300 times); here the
+// sweeps stop once the corrections are rounding noise (below 1e-11 relative and no longer
+// shrinking).  The size of a sweep's corrections is measured as max |q|^2 / (1 + |p|^2) over
+// the roots p and their corrections q -- squares and a reciprocal estimate instead of two square
+// roots and a division per root: the quantity only steers when to stop.
+// live: the row has a polynomial (row-uniform).  All 64 lanes must call.
+__device__ void solve_poly10_rows(const double (&c)[11], int sub, bool live, Cplx& root) {
     {
         Cplx p = {1, 0};
         const Cplx r = {1, 1};
+        root = {0, 0};
 #pragma unroll
         for (int i = 0; i < 10; i++) {
-            roots[i] = p;
+            if (i == sub) root = p;
             p = c_mul(p, r);
         }
     }
+    bool active = live;
     double prev_r2 = DBL_MAX;
     for (int iter = 0; iter < 300; iter++) {
-        double max_r2 = 0;
+        if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+        const Cplx p = root;
+        Cplx num = {c[10], 0};
 #pragma unroll
-        for (int i = 0; i < 10; i++) {
-            const Cplx p = roots[i];
-            Cplx num = {c[10], 0}, denom = {c[10], 0};
+        for (int j = 0; j < 10; j++) {
+            num = c_mul(num, p);
+            num.re += c[9 - j];
+        }
+        Cplx old[10];
+        unroll<10>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            old[J] = {row_bcast<J>(p.re), row_bcast<J>(p.im)};
+        });
+        Cplx fresh[10];         // the roots of this sweep as they are finished
+        Cplx denom = {c[10], 0};  // lane sub: c10 times the factors of the finished roots so far
+        Cplx q = {0, 0};
+        unroll<10>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            // what lane I needs now: the factors of the roots after it (every lane computes on
+            // its own values; only lane I's result is used)
+            Cplx dn = denom;
 #pragma unroll
-            for (int j = 0; j < 10; j++) {
-                num = c_mul(num, p);
-                num.re += c[9 - j];
-                if (j != i) denom = c_mul(denom, Cplx{p.re - roots[j].re, p.im - roots[j].im});
-            }
+            for (int j = I + 1; j < 10; j++) dn = c_mul(dn, Cplx{p.re - old[j].re, p.im - old[j].im});
             // solvePoly leaves a difference that is exactly zero out of the product.  With such
-            // a factor the plain product above is exactly zero (or not a number, after an
-            // overflow): only then are the factors tested one by one.
-            if (!(fabs(denom.re) + fabs(denom.im) > 0)) {
-                denom = {c[10], 0};
+            // a factor the plain product is exactly zero (or not a number, after an overflow):
+            // only then are the factors tested one by one.
+            const bool redo = sub == I && active && !(fabs(dn.re) + fabs(dn.im) > 0);
+            if (__builtin_amdgcn_ballot_w64(redo) != 0) {
+                Cplx d2 = {c[10], 0};
 #pragma unroll
                 for (int j = 0; j < 10; j++) {
-                    if (j == i) continue;
-                    const Cplx d = {p.re - roots[j].re, p.im - roots[j].im};
-                    if (d.re != 0 || d.im != 0) denom = c_mul(denom, d);
+                    if (j == I) continue;
+                    const Cplx rj = j < I ? fresh[j] : old[j];
+                    const Cplx d = {p.re - rj.re, p.im - rj.im};
+                    if (d.re != 0 || d.im != 0) d2 = c_mul(d2, d);
                 }
+                if (redo) dn = d2;
             }
-            const double t = 1. / (denom.re * denom.re + denom.im * denom.im);
-            const Cplx q = {(num.re * denom.re + num.im * denom.im) * t, (-num.re * denom.im + num.im * denom.re) * t};
-            roots[i] = {p.re - q.re, p.im - q.im};
-            const double r2 = (q.re * q.re + q.im * q.im) * __builtin_amdgcn_rcp(1.0 + (p.re * p.re + p.im * p.im));
-            max_r2 = r2 > max_r2 ? r2 : max_r2;
-        }
+            const double t = 1. / (dn.re * dn.re + dn.im * dn.im);
+            const Cplx qi = {(num.re * dn.re + num.im * dn.im) * t, (-num.re * dn.im + num.im * dn.re) * t};
+            const Cplx ri = {p.re - qi.re, p.im - qi.im};
+            if (sub == I) {
+                q = qi;
+                if (active) root = ri;
+            }
+            // the row learns root I; the lanes after it take its factor (the lanes before it no
+            // longer need their product)
+            fresh[I] = {row_bcast<I>(ri.re), row_bcast<I>(ri.im)};
+            denom = c_mul(denom, Cplx{p.re - fresh[I].re, p.im - fresh[I].im});
+        });
+        double r2 = (q.re * q.re + q.im * q.im) * __builtin_amdgcn_rcp(1.0 + (p.re * p.re + p.im * p.im));
+        r2 = sub < 10 && r2 > 0 ? r2 : 0.0;  // also drops a correction that is not a number, as a running maximum does
+        const double max_r2 = row_max(r2);
         // converged: the corrections are at the rounding floor of the Horner evaluation
         // (they stop shrinking once they are tiny) -- or vanish altogether
-        if (!(max_r2 > 1.6e-31) || (max_r2 < 1e-22 && max_r2 > 0.0625 * prev_r2)) break;
+        if (!(max_r2 > 1.6e-31) || (max_r2 < 1e-22 && max_r2 > 0.0625 * prev_r2)) active = false;
         prev_r2 = max_r2;
     }
-#pragma unroll
-    for (int i = 0; i < 10; i++) roots_out[i] = roots[i];
 }
 
-// EMEstimatorCallback::runKernel for five normalised correspondences; up to ten matrices
-// (9 doubles each) to `ematrix`.  `work` is this sample's column of the workgroup's LDS.
-__device__ int five_point(const double2* s1, const double2* s2, Lds work, double* ematrix) {
+// Where the front half of the solver leaves its results for the row (the Lambda area is free
+// by then): the determinant polynomial, or the ten roots when its leading coefficient vanished.
+constexpr int kSolveCz = kSolveQ + kSolveEe, kSolveRz = kSolveCz + 11;
+
+// EMEstimatorCallback::runKernel for five normalised correspondences, first half, run by one
+// lane per sample: everything up to the degree-10 polynomial in z, whose coefficients go to
+// LDS (lowest degree first).  Returns 0: no solution, 1: polynomial stored, 2: the leading
+// coefficient vanished and the roots themselves are stored (generic root finder).
+// `work` is this sample's column of the workgroup's LDS.
+__device__ int five_point_front(const double2* s1, const double2* s2, Lds work) {
     const Lds q = work, ee = q.at(kSolveQ), lam = ee.at(kSolveEe), a = lam.at(kSolveLam), b = a.at(kSolveA);
     for (int i = 0; i < 5; ++i) {
         const double x1 = s1[i].x, y1 = s1[i].y, x2 = s2[i].x, y2 = s2[i].y;
@@ -512,47 +563,61 @@ __device__ int five_point(const double2* s1, const double2* s2, Lds work, double
                     if (u + v <= 10) c[u + v] += kPerm[P][3] * t[u] * pz[2][kPerm[P][2]][v];
         });
     }
-    Cplx roots[10];
-    solve_poly10(c, roots);
-    int count = 0;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        if (fabs(roots[i].im) > 1e-10) continue;
-        const double z1 = roots[i].re, z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
-        double bz[3][3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const Lds br = b.at(13 * j);
-            bz[j][0] = br[0] * z3 + br[1] * z2 + br[2] * z1 + br[3];
-            bz[j][1] = br[4] * z3 + br[5] * z2 + br[6] * z1 + br[7];
-            bz[j][2] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
+    int n = 10;
+    for (; n > 1; n--)
+        if (fabs(c[n]) > DBL_EPSILON) break;
+    if (n < 10) {
+        Cplx roots[10];
+        solve_poly_generic(c, n, roots);
+        for (; n < 10; n++) roots[n] = roots[n - 1];
+        for (int i = 0; i < 10; ++i) {
+            work[kSolveRz + 2 * i] = roots[i].re;
+            work[kSolveRz + 2 * i + 1] = roots[i].im;
         }
-        double best[3] = {0, 0, 0}, best_n2 = -1;
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const double* r0 = bz[u];
-            const double* r1 = bz[(u + 1) % 3];
-            const double v0 = r0[1] * r1[2] - r0[2] * r1[1], v1 = r0[2] * r1[0] - r0[0] * r1[2],
-                         v2 = r0[0] * r1[1] - r0[1] * r1[0];
-            const double n2 = v0 * v0 + v1 * v1 + v2 * v2;
-            if (n2 > best_n2) best_n2 = n2, best[0] = v0, best[1] = v1, best[2] = v2;
-        }
-        if (!(best_n2 > 0)) continue;
-        if (fabs(best[2] * (1.0 / sqrt(best_n2))) < 1e-10) continue;
-        const double x = best[0] / best[2], y = best[1] / best[2];
-        double e9[9];
-        double n2 = 0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            e9[k] = ee[k] * x + ee[9 + k] * y + ee[18 + k] * z1 + ee[27 + k];
-            n2 += e9[k] * e9[k];
-        }
-        const double inv = 1.0 / sqrt(n2);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) ematrix[9 * count + k] = e9[k] * inv;
-        count++;
+        return 2;
     }
-    return count;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) work[kSolveCz + k] = c[k];
+    return 1;
+}
+
+// Second half, one lane per root z (real part z1, imaginary part z_im): (x, y) from the null
+// vector of B(z), the matrix, its normalisation.  Returns whether the root gives a matrix.
+__device__ bool five_point_model(double z1, double z_im, Lds work, double (&e9)[9]) {
+    const Lds ee = work.at(kSolveQ), b = work.at(kSolveQ + kSolveEe + kSolveLam + kSolveA);
+    bool ok = !(fabs(z_im) > 1e-10);
+    const double z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+    double bz[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const Lds br = b.at(13 * j);
+        bz[j][0] = br[0] * z3 + br[1] * z2 + br[2] * z1 + br[3];
+        bz[j][1] = br[4] * z3 + br[5] * z2 + br[6] * z1 + br[7];
+        bz[j][2] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
+    }
+    double best[3] = {0, 0, 0}, best_n2 = -1;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const double* r0 = bz[u];
+        const double* r1 = bz[(u + 1) % 3];
+        const double v0 = r0[1] * r1[2] - r0[2] * r1[1], v1 = r0[2] * r1[0] - r0[0] * r1[2],
+                     v2 = r0[0] * r1[1] - r0[1] * r1[0];
+        const double n2 = v0 * v0 + v1 * v1 + v2 * v2;
+        if (n2 > best_n2) best_n2 = n2, best[0] = v0, best[1] = v1, best[2] = v2;
+    }
+    ok = ok && best_n2 > 0;
+    ok = ok && !(fabs(best[2] * (1.0 / sqrt(best_n2))) < 1e-10);
+    const double x = best[0] / best[2], y = best[1] / best[2];
+    double n2 = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        e9[k] = ee[k] * x + ee[9 + k] * y + ee[18 + k] * z1 + ee[27 + k];
+        n2 += e9[k] * e9[k];
+    }
+    const double inv = 1.0 / sqrt(n2);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e9[k] *= inv;
+    return ok;
 }
 
 // ---- rounds ----------------------------------------------------------------------------------
@@ -751,27 +816,56 @@ __device__ __forceinline__ float sampson(const double (&E)[9], double2 p1, doubl
     return (float)(x2tex1 * x2tex1 / (a + b + c + d));
 }
 
-// One lane per (point set, live iteration of the round): the 5-point solve, sixteen to a
-// workgroup (the LDS their work arrays need).
-__global__ __launch_bounds__(kSolveLanes) void em_solve_kernel(EmArgs a) {
-    __shared__ double s_work[kSolveDoubles * kSolveLanes];
+// The 5-point solves of a round's live iterations, four per workgroup of one wave: a sample
+// has a row of 16 lanes.  Lane 0 of the row runs the front half (a chain of dependent work on
+// one sample); the ten roots are found by ten lanes together; then every lane turns its root
+// into a matrix and the row writes the matrices of the real roots in root order.
+__global__ __launch_bounds__(64) void em_solve_kernel(EmArgs a) {
+    __shared__ double s_work[kSolveDoubles * kSolveRows];
     const int p = blockIdx.y;
     const int count = problem_count(a, p);
     const int end = live_end(a, p, count);
     const double2* m1 = a.m1 + (size_t)p * a.stride;
     const double2* m2 = a.m2 + (size_t)p * a.stride;
-    const Lds work = {s_work + threadIdx.x};
-    for (int it = a.lo + blockIdx.x * kSolveLanes + threadIdx.x; it < end; it += gridDim.x * kSolveLanes) {
-        const size_t slot = (size_t)p * a.max_iters + it;
-        double2 s1[5], s2[5];
+    const int row = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const Lds work = {s_work + row};
+    for (int first = a.lo + blockIdx.x * kSolveRows; first < end; first += gridDim.x * kSolveRows) {
+        const int it = first + row;
+        const bool live = it < end;
+        const size_t slot = (size_t)p * a.max_iters + (live ? it : first);
+        if (sub == 0) {
+            int flag = 0;
+            if (live) {
+                double2 s1[5], s2[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int j = count == 5 ? k : a.subsets[slot * 5 + k];
-            s1[k] = m1[j];
-            s2[k] = m2[j];
+                for (int k = 0; k < 5; ++k) {
+                    const int j = count == 5 ? k : a.subsets[slot * 5 + k];
+                    s1[k] = m1[j];
+                    s2[k] = m2[j];
+                }
+                flag = five_point_front(s1, s2, work);
+            }
+            work[kSolveCz + 31] = (double)flag;
         }
-        a.n_models[slot] = five_point(s1, s2, work, a.models + slot * kMaxModels * 9);
-        for (int m = 0; m < kMaxModels; ++m) a.scores[slot * kMaxModels + m] = 0;
+        __syncthreads();
+        const int flag = (int)work[kSolveCz + 31];
+        double c[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) c[k] = flag == 1 ? work[kSolveCz + k] : (k == 10 ? 1.0 : 0.0);
+        Cplx root;
+        solve_poly10_rows(c, sub, flag == 1, root);
+        if (flag == 2 && sub < 10) root = {work[kSolveRz + 2 * sub], work[kSolveRz + 2 * sub + 1]};
+        double e9[9];
+        const bool ok = five_point_model(root.re, root.im, work, e9) && flag != 0 && sub < 10;
+        const unsigned row_ok = (unsigned)(__builtin_amdgcn_ballot_w64(ok) >> (16 * row)) & 0xFFFFu;
+        if (ok) {
+            double* out = a.models + slot * kMaxModels * 9 + 9 * __popc(row_ok & ((1u << sub) - 1u));
+#pragma unroll
+            for (int k = 0; k < 9; ++k) out[k] = e9[k];
+        }
+        if (live && sub == 0) a.n_models[slot] = __popc(row_ok);
+        if (live && sub < kMaxModels) a.scores[slot * kMaxModels + sub] = 0;
+        __syncthreads();  // the next sample's front half overwrites the work arrays
     }
 }
 
@@ -1006,8 +1100,8 @@ int sfm_find_essential_dev(sfm_ctx* ctx, const float* d_pts1, const float* d_pts
         }
         {
             KernelTimer timer(ctx, KID_EM_SOLVE);
-            hipLaunchKernelGGL(em_solve_kernel, dim3(std::min((hi - lo + kSolveLanes - 1) / kSolveLanes, 64), n_problems),
-                               dim3(kSolveLanes), 0, s, a);
+            hipLaunchKernelGGL(em_solve_kernel, dim3(std::min((hi - lo + kSolveRows - 1) / kSolveRows, 64), n_problems),
+                               dim3(64), 0, s, a);
             SFM_HIP_CHECK(ctx, hipGetLastError());
         }
         {
