@@ -725,7 +725,27 @@ __global__ __launch_bounds__(256) void pose_cheirality_kernel(PoseArgs a) {
                 At[j][2] = x2 * P[8 + j] - P[j];
                 At[j][3] = y2 * P[8 + j] - P[4 + j];
             }
-            null_vector_jacobi(At, q);
+            // the null vector as in the triangulation kernels: the fixed-cost inverse iteration,
+            // for the lanes it does not settle the adaptive one, then one-sided Jacobi (what
+            // cv::triangulatePoints runs); the slower solvers only run when a lane of the wave
+            // needs them
+            bool solved = null_vector_invit3(At, q);
+            if (__any(!solved)) {
+                double q2[4];
+                const bool ok2 = null_vector_invit(At, q2);
+                if (!solved) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q[j] = q2[j];
+                    solved = ok2;
+                }
+                if (__any(!solved)) {
+                    null_vector_jacobi(At, q2);
+                    if (!solved) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) q[j] = q2[j];
+                    }
+                }
+            }
             bool pass = q[2] * q[3] > 0;
             const double X = q[0] / q[3], Y = q[1] / q[3], Z = q[2] / q[3];
             pass = pass && Z < a.dist;
