@@ -20,6 +20,7 @@
 // every other operation is the float / fixed-point operation OpenCV performs, in
 // the same order, with FP contraction disabled.
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 
@@ -563,9 +564,8 @@ __device__ __forceinline__ uint32_t pack_shr9(int s0, int s1) {
 // as three pairs and a single.  The sums are at least 1: the only negative weight is -1.
 // The two rows sit at base + o and base + o + S; base is wave-uniform and both offsets are
 // 32-bit, so the loads need no 64-bit address arithmetic per lane.
-__device__ __forceinline__ void window_interp(const uint8_t* base, unsigned o, int S, const Weights& wt,
+__device__ __forceinline__ void window_interp(uint2 a, uint2 b, const Weights& wt,
                                               uint32_t& p01, uint32_t& p23, uint32_t& p45, int& p6) {
-    const uint2 a = load_u8x8(base + o), b = load_u8x8(base + (o + (unsigned)S));
     const uint32_t c0 = col_pair<0>(a, b), c1 = col_pair<1>(a, b), c2 = col_pair<2>(a, b),
                    c3 = col_pair<3>(a, b), c4 = col_pair<4>(a, b), c5 = col_pair<5>(a, b),
                    c6 = col_pair<6>(a, b), c7 = col_pair<7>(a, b);
@@ -577,6 +577,10 @@ __device__ __forceinline__ void window_interp(const uint8_t* base, unsigned o, i
     p01 = pack_shr9(s0, s1);
     p23 = pack_shr9(s2, s3);
     p45 = pack_shr9(s4, s5);
+}
+__device__ __forceinline__ void window_interp(const uint8_t* base, unsigned o, int S, const Weights& wt,
+                                              uint32_t& p01, uint32_t& p23, uint32_t& p45, int& p6) {
+    window_interp(load_u8x8(base + o), load_u8x8(base + (o + (unsigned)S)), wt, p01, p23, p45, p6);
 }
 
 // LPP = lanes per point: 64 (one point per wave) or 16 (four points per wave, one per
@@ -755,6 +759,12 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
         next_x -= half_x;
         next_y -= half_y;
         float prev_dx = 0.f, prev_dy = 0.f;
+        // The two rows of bytes every slot reads from J, kept from one iteration to the next:
+        // once the steps are below a pixel the window's integer position mostly stays where it
+        // was, and the loads (what this kernel waits for most) are issued only for the points
+        // whose position changed.
+        uint2 ja[SPL], jb[SPL];
+        int held_x = INT_MIN, held_y = INT_MIN;
 
         for (int j = 0; j < a.max_count; ++j) {
             const int inx = (int)floorf(next_x), iny = (int)floorf(next_y);
@@ -765,13 +775,22 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
             wt = bilinear_weights(next_x - inx, next_y - iny);
             int pb[2] = {0, 0};
             const unsigned jbase = (unsigned)((iny + g.bh) * S + inx + g.bw);
+            if (inx != held_x || iny != held_y) {
+#pragma unroll
+                for (int s = 0; s < SPL; ++s) {
+                    const unsigned o = jbase + soff[s];
+                    ja[s] = load_u8x8(J + o);
+                    jb[s] = load_u8x8(J + (o + (unsigned)S));
+                }
+                held_x = inx;
+                held_y = iny;
+            }
 #pragma unroll
             for (int s = 0; s < SPL; ++s) {
                 const SlotWin& w = win[s];
-                const unsigned o = jbase + soff[s];
                 uint32_t j01, j23, j45;
                 int j6;
-                window_interp(J, o, S, wt, j01, j23, j45, j6);
+                window_interp(ja[s], jb[s], wt, j01, j23, j45, j6);
                 // mismatch J - I; the derivative pairs are 0 outside the window
                 const uint32_t d01 = pk_sub_i16(j01, w.i01), d23 = pk_sub_i16(j23, w.i23),
                                d45 = pk_sub_i16(j45, w.i45);
