@@ -6,8 +6,10 @@
 //                            over the image through LDS tiles; image maximum by atomics.
 //   2. corner_pick_kernel    threshold at max * qualityLevel, 3x3 local maxima of the interior,
 //                            appended as sortable keys (image << 58 | value bits << 26 | y * w + x).
-//   3. radix sort, descending: by value, ties by address, both descending, as OpenCV's
-//      std::sort with greaterThanPtr orders its pointers.
+//   3. corner_sort_kernel    radix sort of an image's candidates, descending: by value, ties by
+//                            address, both descending, as OpenCV's std::sort with greaterThanPtr
+//                            orders its pointers.  One workgroup per image; only the candidates
+//                            found are sorted, not the capacity of the list.
 //   4. corner_rank_kernel    position -> rank image (which also carries each candidate's state).
 //   5. corner_select_kernel  the greedy minimum-distance pass.  Sequentially, a candidate is
 //                            kept unless an already kept one is closer than minDistance (the
@@ -27,10 +29,9 @@
 //                            sequential pass settles whatever a fixed number of rounds left open.
 //   6. corner_emit_kernel    the kept candidates, in rank order, up to maxCorners.
 //
-// Every kernel takes a batch of equally sized images (one grid dimension is the image); the
-// candidates of all images are sorted by ONE radix sort, the image number riding in the top
-// bits of the key.  For a single 1280x720 frame two thirds of the time are launch gaps between
-// ~30 short kernels; a batch shares them.
+// Every kernel takes a batch of equally sized images (one grid dimension is the image).  For a
+// single 1280x720 frame most of the time are launch gaps between ~20 short kernels; a batch
+// shares them.
 //
 // All float arithmetic is unfused and ordered as in the CPU restatement: Sobel smoothing
 // (s0 + s2) * k1 + s1 * k0 with the scale 1 / (4 * 3 * 255) folded into the taps, box sums
@@ -41,7 +42,6 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "sfm_internal.h"
 
@@ -80,7 +80,7 @@ struct CornerArgs {
 };
 
 // The arguments of image `im` of the batch: every per-image array moved to its slice.  The
-// sorted keys of image im follow those of the images above it (descending sort).
+// candidates of an image are sorted inside its own slice.
 __device__ __forceinline__ CornerArgs image_view(CornerArgs a, int im) {
     const size_t px = (size_t)a.w * a.h;
     a.image = im;
@@ -90,7 +90,7 @@ __device__ __forceinline__ CornerArgs image_view(CornerArgs a, int im) {
     a.max_bits += (size_t)im * kCtrlWords;
     a.counters += (size_t)im * kCtrlWords;
     a.keys += (size_t)im * a.cap;
-    a.sorted += (size_t)(a.n_images - 1 - im) * a.cap;
+    a.sorted += (size_t)im * a.cap;
     a.state += (size_t)im * a.cap;
     a.corners += (size_t)im * a.cap_out;
     a.info += 3 * im;
@@ -188,13 +188,6 @@ __global__ __launch_bounds__(256) void corner_eig_kernel(CornerArgs batch) {
     if (tid == 0 && s_max) atomicMax(a.max_bits, s_max);
 }
 
-// Unused key slots sort behind the candidates of their own image.
-__global__ void corner_fill_kernel(CornerArgs batch) {
-    const size_t total = (size_t)batch.n_images * batch.cap;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-        batch.keys[i] = (unsigned long long)(i / batch.cap) << kImageShift;
-}
-
 constexpr int kPickRows = 32;  // rows per workgroup of the candidate pass (8 per wave)
 
 __global__ __launch_bounds__(256) void corner_pick_kernel(CornerArgs batch) {
@@ -269,6 +262,110 @@ __device__ __forceinline__ int load_state(const CornerArgs& a, int i) {
 __device__ __forceinline__ void store_state(const CornerArgs& a, int i, unsigned pos, int s) {
     __hip_atomic_store(a.state + i, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(a.rank + pos, i | (s << kStateShift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The candidates of an image in descending key order (value, then position: OpenCV sorts by
+// value and breaks ties by the higher address first): a stable least-significant-digit radix
+// sort, eight passes of eight bits, by one workgroup of 16 waves per image, between the two
+// key arrays (the result is back in `keys` after the eighth pass).  Every wave owns a
+// contiguous share of the list; per pass it counts its digits, the workgroup turns the counts
+// into start positions (digit major, wave minor), and the wave walks its share again and
+// places every key: keys of a 64-key tile with the same digit find their order among
+// themselves from ballots.
+constexpr int kSortWaves = 16, kSortAhead = 8;
+__global__ __launch_bounds__(64 * kSortWaves) void corner_sort_kernel(CornerArgs batch) {
+    const CornerArgs a = image_view(batch, blockIdx.x);
+    const int n = candidate_count(a);
+    __shared__ unsigned s_count[kSortWaves][256];  // then: next free position per (wave, digit)
+    __shared__ unsigned s_total[256];
+    __shared__ unsigned s_wave_sum[4];
+    __shared__ int s_one_digit;  // all keys share this pass's digit: the pass is a plain copy
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int share = (((n + kSortWaves - 1) / kSortWaves) + 63) & ~63;
+    const int begin = min(wave * share, n), end = min(begin + share, n);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned long long* src = a.keys;
+    unsigned long long* dst = a.sorted;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 8 * pass;
+        // lanes of the tile that hold the same digit (descending order: digit 255 first)
+        auto same_digit = [&](bool valid, unsigned long long key, unsigned& digit) {
+            digit = 255u - (unsigned)((key >> shift) & 255u);
+            unsigned long long m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (digit >> b) & 1u;
+                const unsigned long long v = __ballot(bit);
+                m &= bit ? v : ~v;
+            }
+            return m;
+        };
+        for (int i = lane; i < 256; i += 64) s_count[wave][i] = 0;
+        if (tid == 0) s_one_digit = 0;
+        // one wave touches its own row of the table only, in program order: no barrier needed
+        for (int i0 = begin; i0 < end; i0 += 64 * kSortAhead) {
+            unsigned long long keys[kSortAhead];  // the loads of several tiles in flight at once
+#pragma unroll
+            for (int u = 0; u < kSortAhead; ++u) keys[u] = i0 + 64 * u + lane < end ? src[i0 + 64 * u + lane] : 0ull;
+#pragma unroll
+            for (int u = 0; u < kSortAhead; ++u) {
+                const bool valid = i0 + 64 * u + lane < end;
+                unsigned digit;
+                const unsigned long long m = same_digit(valid, keys[u], digit);
+                if (valid && (m & below) == 0) s_count[wave][digit] += (unsigned)__popcll(m);
+            }
+        }
+        __syncthreads();
+        // start positions: all keys of smaller digits, then the same digit in earlier waves
+        unsigned mine = 0;
+        if (tid < 256) {
+            for (int w = 0; w < kSortWaves; ++w) {
+                const unsigned c = s_count[w][tid];
+                s_count[w][tid] = mine;
+                mine += c;
+            }
+            unsigned incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            if (lane == 63) s_wave_sum[wave] = incl;
+            if (mine == (unsigned)n) s_one_digit = 1;
+            s_total[tid] = incl - mine;  // exclusive within the wave
+        }
+        __syncthreads();
+        if (tid < 256) {
+            unsigned base = s_total[tid];
+            for (int w = 0; w < wave; ++w) base += s_wave_sum[w];
+            for (int w = 0; w < kSortWaves; ++w) s_count[w][tid] += base;
+        }
+        __syncthreads();
+        if (s_one_digit) {
+            for (int i = begin + lane; i < end; i += 64) dst[i] = src[i];
+        } else
+        for (int i0 = begin; i0 < end; i0 += 64 * kSortAhead) {
+            unsigned long long keys[kSortAhead];
+#pragma unroll
+            for (int u = 0; u < kSortAhead; ++u) keys[u] = i0 + 64 * u + lane < end ? src[i0 + 64 * u + lane] : 0ull;
+#pragma unroll
+            for (int u = 0; u < kSortAhead; ++u) {
+                const bool valid = i0 + 64 * u + lane < end;
+                unsigned digit;
+                const unsigned long long m = same_digit(valid, keys[u], digit);
+                unsigned at = 0;
+                if (valid) at = s_count[wave][digit] + (unsigned)__popcll(m & below);
+                // every lane has read the position of its digit before the digit's first lane moves it on
+                __builtin_amdgcn_wave_barrier();
+                if (valid && (m & below) == 0) s_count[wave][digit] += (unsigned)__popcll(m);
+                if (valid) dst[at] = keys[u];
+            }
+        }
+        __syncthreads();  // also orders this pass's stores before the next pass's loads
+        unsigned long long* t = src;
+        src = dst;
+        dst = t;
+    }
 }
 
 // Ranks and the first prefix to work on.
@@ -442,21 +539,12 @@ int default_capacity(int w, int h) {
     return (int)std::min<size_t>(px, px / 4 + 1024);
 }
 
-size_t sort_temp_bytes(size_t slots) {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_keys_desc(nullptr, bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                        slots, 0, 64, nullptr);
-    return bytes;
-}
-
 struct CornerBuffers {
     float* eig;
     int32_t* rank;
     unsigned long long *keys, *sorted;
     int32_t* state;
     unsigned* ctrl;  // per image kCtrlWords: the maximum, then the counters
-    void* sort_temp;
-    size_t sort_bytes;
 };
 
 CornerBuffers carve_corners(Carver& c, int n_images, int w, int h, int cap) {
@@ -469,8 +557,6 @@ CornerBuffers carve_corners(Carver& c, int n_images, int w, int h, int cap) {
     b.state = c.take<int32_t>(slots);
     b.ctrl = c.take<unsigned>((size_t)kCtrlWords * n_images);
     static_assert(4 + C_COUNT <= kCtrlWords, "the counters fit the cleared block");
-    b.sort_bytes = sort_temp_bytes(slots);
-    b.sort_temp = c.take<char>(b.sort_bytes);
     return b;
 }
 
@@ -513,17 +599,17 @@ int run_corners(sfm_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_
     }
     {
         KernelTimer timer(ctx, KID_CORNER_PICK);
-        hipLaunchKernelGGL(corner_fill_kernel, dim3((unsigned)std::min<size_t>((slots + 255) / 256, 4096)), dim3(256), 0, s,
-                           a);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
         hipLaunchKernelGGL(corner_pick_kernel, dim3((w - 2 + 63) / 64, (h - 2 + kPickRows - 1) / kPickRows, n), dim3(256),
                            0, s, a);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
     {
         KernelTimer timer(ctx, KID_CORNER_SORT);
-        size_t bytes = b.sort_bytes;
-        SFM_HIP_CHECK(ctx, rocprim::radix_sort_keys_desc(b.sort_temp, bytes, b.keys, b.sorted, slots, 0, 64, s));
+        hipLaunchKernelGGL(corner_sort_kernel, dim3(n), dim3(64 * kSortWaves), 0, s, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+        // eight passes: the sorted list is in the array the candidates were appended to
+        a.sorted = b.keys;
+        a.keys = b.sorted;
     }
     {
         KernelTimer timer(ctx, KID_CORNER_SELECT);
