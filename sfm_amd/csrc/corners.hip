@@ -56,7 +56,9 @@ constexpr int kMaxDistance = 128;  // largest minDistance: the disc's offsets ar
 enum { C_FOUND = 0, C_OVERFLOW, C_OPEN, C_KEPT = C_OPEN + kSelectRounds, C_COUNT = C_KEPT + kSelectRounds };
 constexpr int kStateShift = 30;  // rank image entries: rank | state << 30, or -1
 constexpr int kPosBits = 26, kImageShift = 58, kMaxImages = 64;  // key = image | value bits | position
-constexpr int kCtrlWords = 64;  // cleared words per image: maximum, counters
+constexpr int kBuckets = 64;     // value ranges an image's candidates are split into before the sort
+constexpr int kCtrlWords = 64 + 2 * kBuckets;  // cleared words per image: maximum, counters; bucket sizes, bucket starts
+constexpr int kBucketWord = 64 - 4;  // first bucket word, counted from the counters
 
 struct CornerArgs {
     const uint8_t* img;
@@ -264,28 +266,127 @@ __device__ __forceinline__ void store_state(const CornerArgs& a, int i, unsigned
     __hip_atomic_store(a.rank + pos, i | (s << kStateShift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// The candidates of an image in descending key order (value, then position: OpenCV sorts by
-// value and breaks ties by the higher address first): a stable least-significant-digit radix
-// sort, eight passes of eight bits, by one workgroup of 16 waves per image, between the two
-// key arrays (the result is back in `keys` after the eighth pass).  Every wave owns a
-// contiguous share of the list; per pass it counts its digits, the workgroup turns the counts
-// into start positions (digit major, wave minor), and the wave walks its share again and
-// places every key: keys of a 64-key tile with the same digit find their order among
-// themselves from ballots.
-constexpr int kSortWaves = 16, kSortAhead = 8;
-__global__ __launch_bounds__(64 * kSortWaves) void corner_sort_kernel(CornerArgs batch) {
+// Fine value bin of a key: the value range [threshold, maximum] of the image cut into kFineBins
+// equal steps of the ordered value bits, the highest values in bin 0.  Monotone in the key.
+constexpr int kFineBins = 2048;
+__device__ __forceinline__ int key_fine_bin(unsigned long long key, unsigned lo, float scale) {
+    const unsigned vb = (unsigned)(key >> kPosBits);
+    const unsigned rel = vb > lo ? vb - lo : 0u;
+    // float arithmetic is monotone in rel, which is all the split needs
+    const int b = (int)((float)rel * scale);
+    return kFineBins - 1 - min(b, kFineBins - 1);
+}
+
+// Splits the candidates of an image (keys, in the order they were found) by value into
+// `sorted`: bucket 0 (the highest values) first, any order inside a bucket.  The buckets are
+// runs of fine value bins of about equal population (a histogram over kFineBins bins, cut where
+// the running count passes multiples of n / kBuckets), so that the workgroups that sort them
+// get equal work whatever the distribution of the values.  Sizes and starts of the buckets go
+// to the image's control words.  One workgroup per image.
+__global__ __launch_bounds__(1024) void corner_split_kernel(CornerArgs batch) {
     const CornerArgs a = image_view(batch, blockIdx.x);
     const int n = candidate_count(a);
+    __shared__ unsigned s_fine[kFineBins];      // population, then bucket of the bin
+    __shared__ unsigned s_wave_total[16];
+    __shared__ unsigned s_size[kBuckets], s_next[kBuckets];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    s_fine[tid] = 0;
+    s_fine[tid + 1024] = 0;
+    if (tid < kBuckets) s_size[tid] = 0;
+    __syncthreads();
+    const unsigned hi = *a.max_bits;
+    const unsigned lo = min(ordered_bits((float)((double)from_ordered_bits(hi) * a.quality)), hi);
+    const float scale = (float)kFineBins / ((float)(hi - lo) + 1.f);
+    for (int i = tid; i < n; i += 1024) atomicAdd(&s_fine[key_fine_bin(a.keys[i], lo, scale)], 1u);
+    __syncthreads();
+    // running count before each bin (thread t: bins 2t, 2t + 1), bucket = where it falls in n
+    const unsigned c0 = s_fine[2 * tid], c1 = s_fine[2 * tid + 1];
+    unsigned incl = c0 + c1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) s_wave_total[wave] = incl;
+    __syncthreads();
+    unsigned before = incl - (c0 + c1);
+    for (int w = 0; w < wave; ++w) before += s_wave_total[w];
+    const unsigned per = (unsigned)(n + kBuckets - 1) / kBuckets + 1u;
+    const unsigned b0 = min(before / per, (unsigned)(kBuckets - 1));
+    const unsigned b1 = min((before + c0) / per, (unsigned)(kBuckets - 1));
+    s_fine[2 * tid] = b0;
+    s_fine[2 * tid + 1] = b1;
+    if (c0) atomicAdd(&s_size[b0], c0);
+    if (c1) atomicAdd(&s_size[b1], c1);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned at = 0;
+        for (int b = 0; b < kBuckets; ++b) {
+            a.counters[kBucketWord + b] = (int)s_size[b];
+            a.counters[kBucketWord + kBuckets + b] = (int)at;
+            s_next[b] = at;
+            at += s_size[b];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const unsigned long long key = a.keys[i];
+        a.sorted[atomicAdd(&s_next[s_fine[key_fine_bin(key, lo, scale)]], 1u)] = key;
+    }
+}
+
+// One bucket of an image's candidates (in `sorted`) into descending key order (value, then
+// position: OpenCV sorts by value and breaks ties by the higher address first), so that the
+// whole list is in order: a stable least-significant-digit radix sort, eight passes of eight
+// bits, by one workgroup of 16 waves.  A pass whose digit is the same for all keys (the bits
+// that made the bucket, the image number) is a plain copy.  Every wave owns a contiguous share
+// of the list; per pass it counts its digits, the workgroup turns the counts into start
+// positions (digit major, wave minor), and the wave walks its share again and places every
+// key: keys of a 64-key tile with the same digit find their order among themselves from
+// ballots.  That is the path of a bucket above kSortLdsKeys keys (many equal values); the
+// usual bucket, a few hundred keys, is sorted inside LDS by a bitonic network instead (the keys
+// are all different -- they carry their position -- so an unstable sort gives the same order).
+constexpr int kSortWaves = 16, kSortAhead = 4, kSortLdsKeys = 2048;
+__global__ __launch_bounds__(64 * kSortWaves) void corner_sort_kernel(CornerArgs batch) {
+    const CornerArgs a = image_view(batch, blockIdx.y);
+    const int n = a.counters[kBucketWord + blockIdx.x];
+    if (n < 2) return;  // workgroup-uniform
+    const int first = a.counters[kBucketWord + kBuckets + blockIdx.x];
     __shared__ unsigned s_count[kSortWaves][256];  // then: next free position per (wave, digit)
     __shared__ unsigned s_total[256];
     __shared__ unsigned s_wave_sum[4];
     __shared__ int s_one_digit;  // all keys share this pass's digit: the pass is a plain copy
+    __shared__ unsigned long long s_keys[kSortLdsKeys];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (n <= kSortLdsKeys) {
+        unsigned long long* io = a.sorted + first;
+        int padded = 2;
+        while (padded < n) padded <<= 1;
+        for (int i = tid; i < padded; i += 64 * kSortWaves) s_keys[i] = i < n ? io[i] : 0ull;  // 0 sorts last
+        __syncthreads();
+        for (int k = 2; k <= padded; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < padded; i += 64 * kSortWaves) {
+                    const int other = i ^ j;
+                    if (other > i) {
+                        const unsigned long long x = s_keys[i], y = s_keys[other];
+                        const bool descending = (i & k) == 0;
+                        if ((x < y) == descending) {
+                            s_keys[i] = y;
+                            s_keys[other] = x;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < n; i += 64 * kSortWaves) io[i] = s_keys[i];
+        return;
+    }
     const int share = (((n + kSortWaves - 1) / kSortWaves) + 63) & ~63;
     const int begin = min(wave * share, n), end = min(begin + share, n);
     const unsigned long long below = (1ull << lane) - 1ull;
-    unsigned long long* src = a.keys;
-    unsigned long long* dst = a.sorted;
+    unsigned long long* src = a.sorted + first;
+    unsigned long long* dst = a.keys + first;
     for (int pass = 0; pass < 8; ++pass) {
         const int shift = 8 * pass;
         // lanes of the tile that hold the same digit (descending order: digit 255 first)
@@ -343,22 +444,23 @@ __global__ __launch_bounds__(64 * kSortWaves) void corner_sort_kernel(CornerArgs
         __syncthreads();
         if (s_one_digit) {
             for (int i = begin + lane; i < end; i += 64) dst[i] = src[i];
-        } else
-        for (int i0 = begin; i0 < end; i0 += 64 * kSortAhead) {
-            unsigned long long keys[kSortAhead];
+        } else {
+            for (int i0 = begin; i0 < end; i0 += 64 * kSortAhead) {
+                unsigned long long keys[kSortAhead];
 #pragma unroll
-            for (int u = 0; u < kSortAhead; ++u) keys[u] = i0 + 64 * u + lane < end ? src[i0 + 64 * u + lane] : 0ull;
+                for (int u = 0; u < kSortAhead; ++u) keys[u] = i0 + 64 * u + lane < end ? src[i0 + 64 * u + lane] : 0ull;
 #pragma unroll
-            for (int u = 0; u < kSortAhead; ++u) {
-                const bool valid = i0 + 64 * u + lane < end;
-                unsigned digit;
-                const unsigned long long m = same_digit(valid, keys[u], digit);
-                unsigned at = 0;
-                if (valid) at = s_count[wave][digit] + (unsigned)__popcll(m & below);
-                // every lane has read the position of its digit before the digit's first lane moves it on
-                __builtin_amdgcn_wave_barrier();
-                if (valid && (m & below) == 0) s_count[wave][digit] += (unsigned)__popcll(m);
-                if (valid) dst[at] = keys[u];
+                for (int u = 0; u < kSortAhead; ++u) {
+                    const bool valid = i0 + 64 * u + lane < end;
+                    unsigned digit;
+                    const unsigned long long m = same_digit(valid, keys[u], digit);
+                    unsigned at = 0;
+                    if (valid) at = s_count[wave][digit] + (unsigned)__popcll(m & below);
+                    // every lane has read the position of its digit before the digit's first lane moves it on
+                    __builtin_amdgcn_wave_barrier();
+                    if (valid && (m & below) == 0) s_count[wave][digit] += (unsigned)__popcll(m);
+                    if (valid) dst[at] = keys[u];
+                }
             }
         }
         __syncthreads();  // also orders this pass's stores before the next pass's loads
@@ -366,6 +468,7 @@ __global__ __launch_bounds__(64 * kSortWaves) void corner_sort_kernel(CornerArgs
         src = dst;
         dst = t;
     }
+    // eight passes: the result is where the bucket started, in `sorted`
 }
 
 // Ranks and the first prefix to work on.
@@ -556,7 +659,7 @@ CornerBuffers carve_corners(Carver& c, int n_images, int w, int h, int cap) {
     b.sorted = c.take<unsigned long long>(slots);
     b.state = c.take<int32_t>(slots);
     b.ctrl = c.take<unsigned>((size_t)kCtrlWords * n_images);
-    static_assert(4 + C_COUNT <= kCtrlWords, "the counters fit the cleared block");
+    static_assert(4 + C_COUNT <= 64, "the counters end before the bucket words");
     return b;
 }
 
@@ -605,11 +708,10 @@ int run_corners(sfm_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_
     }
     {
         KernelTimer timer(ctx, KID_CORNER_SORT);
-        hipLaunchKernelGGL(corner_sort_kernel, dim3(n), dim3(64 * kSortWaves), 0, s, a);
+        hipLaunchKernelGGL(corner_split_kernel, dim3(n), dim3(1024), 0, s, a);
         SFM_HIP_CHECK(ctx, hipGetLastError());
-        // eight passes: the sorted list is in the array the candidates were appended to
-        a.sorted = b.keys;
-        a.keys = b.sorted;
+        hipLaunchKernelGGL(corner_sort_kernel, dim3(kBuckets, n), dim3(64 * kSortWaves), 0, s, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
     }
     {
         KernelTimer timer(ctx, KID_CORNER_SELECT);

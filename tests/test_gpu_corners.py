@@ -109,6 +109,19 @@ def test_plateaus_and_candidate_overflow(ctx, oracle):
     assert np.array_equal(d_pts.cpu().numpy()[: info[0]], want)
 
 
+def test_thousands_of_equal_strengths(ctx, oracle):
+    """A large image of constant blocks: a handful of distinct strengths, thousands of
+    candidates each.  Candidates of one strength fall into one value bucket, far more than the
+    in-LDS sort of a bucket takes, so the radix path orders them -- by descending address, as
+    OpenCV's pointer comparison does."""
+    rng = np.random.default_rng(17)
+    img = np.kron(rng.integers(0, 2, size=(120, 160)).astype(np.uint8) * 180 + 20, np.ones((4, 4), np.uint8))
+    want, ncand = oracle.good_features(img, 3000, 0.01, 3.0, return_candidates=True)
+    assert ncand > 15000 and len(want) > 500
+    pts = ctx.good_features(img, 3000, 0.01, 3.0)
+    assert np.array_equal(pts, want)
+
+
 def test_dependency_chain_longer_than_the_rounds(ctx, oracle):
     """A ramp of strictly decreasing strengths along a line, spaced closer than minDistance:
     candidate k depends on k-1, so the parallel rounds cannot finish and the sequential pass
