@@ -123,7 +123,20 @@ def dist_setup(n_gpus, force_group=False):
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout is for
+        # the one JSON line, so the banner goes to stderr
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            warm = torch.zeros(1, device=torch.device("cuda", local))
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
     else:
         torch.cuda.set_device(0)
         local = 0
@@ -318,15 +331,28 @@ def run_framepair(args, rank, world, local):
     # N > 1: every rank matches its own pairs, then all ranks exchange their match lists
     # (fixed-capacity buffers + counts, no host round trip); the collective is asynchronous
     # and overlaps the tracking kernels of the same step.
-    gather = allpairs.PaddedGather(P, cap, world, dev) if world > 1 or args.force_gather else None
+    # The exchanged lists are the compact 6-byte records (a third of the bytes of the DMatch
+    # buffers); the matcher then writes them back to back, still without a host round trip.
+    compact = os.environ.get('SFM_BENCH_GATHER', 'compact') == 'compact'
+    gather = allpairs.PaddedGather(P, cap, world, dev, compact=compact) if world > 1 or args.force_gather else None
     gathered = {}
+    if gather is not None:
+        d_compact = torch.empty((P * cap, 3), dtype=torch.int16, device=dev)
+        d_offsets = torch.empty(P + 1, dtype=torch.int64, device=dev)
+        ctx.reserve(capi.Context.match_pairs_compact_workspace(0, P + 1, KPS, DESC_BYTES, P))
+        torch.cuda.synchronize()
 
     def make_step(track_ctx):
         def step():
-            ctx.match_pairs_dev(capi.NORM_HAMMING, d_desc, P + 1, KPS * DESC_BYTES, KPS, None,
-                                DESC_BYTES, d_pairs, P, 0.5, d_matches, cap, d_mcount)
-            if gather is not None:
-                gather.start(d_matches, d_mcount)
+            if gather is None or not compact:
+                ctx.match_pairs_dev(capi.NORM_HAMMING, d_desc, P + 1, KPS * DESC_BYTES, KPS, None,
+                                    DESC_BYTES, d_pairs, P, 0.5, d_matches, cap, d_mcount)
+                if gather is not None:
+                    gather.start(d_matches, d_mcount)
+            else:
+                ctx.match_pairs_compact_dev(capi.NORM_HAMMING, d_desc, P + 1, KPS * DESC_BYTES, KPS, None,
+                                            DESC_BYTES, d_pairs, P, 0.5, d_compact, P * cap, d_mcount, d_offsets)
+                gather.start(d_compact, d_mcount)
             track_ctx.pyrlk_batch_dev(d_prev, d_curr, P, LK_W * LK_H, LK_W, LK_H, LK_W, d_pts, LK_POINTS,
                                       LK_WIN, LK_MAXLEVEL, 3, LK_COUNT, LK_EPS, 1e-4, 10.0, d_out,
                                       d_status, d_err)

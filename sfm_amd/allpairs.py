@@ -104,17 +104,21 @@ def gather_segments_host(src, src_off, dst_off, lens, total):
 class PaddedGather:
     """All-gather of fixed-capacity match buffers with no host synchronisation.
 
-    Every rank contributes its [P, cap, 4] int32 match buffer (cv::DMatch layout) and its [P]
-    counts as they are; `start` only enqueues the two collectives (asynchronously, so kernels
-    launched afterwards overlap them) and `wait` makes the current stream wait for them.  The
-    gathered tensors are [world, P, cap, 4] and [world, P]: rank r's pair p is at [r, p].
-    Meant for per-frame-pair use, where P is small and a compaction would cost a host round
-    trip per step; windowed matching over many pairs uses `match_all_pairs`.
+    Every rank contributes a match buffer of `payload_shape` and its [P] counts as they are;
+    `start` only enqueues the two collectives (asynchronously, so kernels launched afterwards
+    overlap them) and `wait` makes the current stream wait for them.  The gathered tensors are
+    [world, *payload_shape] and [world, P].  The payload is either the [P, cap, 4] int32 buffer
+    of cv::DMatch records (rank r's pair p at [r, p]) or, at 6 instead of 16 bytes per match, the
+    [P * cap, 3] int16 buffer the compact matcher fills back to back (rank r's pair p starts at
+    the sum of r's counts before p; only that prefix of a rank's slice is meaningful).
+    Meant for per-frame-pair use, where P is small and sizing the exchange by the counts would
+    cost a host round trip per step; windowed matching over many pairs uses `match_all_pairs`.
     """
 
-    def __init__(self, P, cap, world, device, group=None):
+    def __init__(self, P, cap, world, device, group=None, compact=False):
         self.world, self.group = world, group
-        self.matches = torch.empty((world, P, cap, 4), dtype=torch.int32, device=device)
+        shape, dtype = ((P * cap, 3), torch.int16) if compact else ((P, cap, 4), torch.int32)
+        self.matches = torch.empty((world,) + shape, dtype=dtype, device=device)
         self.counts = torch.empty((world, P), dtype=torch.int32, device=device)
         self._work = ()
 
@@ -122,8 +126,9 @@ class PaddedGather:
         self._work = (
             dist.all_gather_into_tensor(self.counts.view(-1), d_counts.view(-1), group=self.group,
                                         async_op=True),
-            dist.all_gather_into_tensor(self.matches.view(-1), d_matches.view(-1), group=self.group,
-                                        async_op=True),
+            # as bytes: the process group takes no 16-bit integers
+            dist.all_gather_into_tensor(self.matches.view(-1).view(torch.uint8),
+                                        d_matches.view(-1).view(torch.uint8), group=self.group, async_op=True),
         )
 
     def wait(self):

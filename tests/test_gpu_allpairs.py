@@ -145,6 +145,18 @@ def test_collectives_with_a_one_rank_rccl_group(env, oracle):
         torch.cuda.synchronize()
         np.testing.assert_array_equal(g.counts[0].cpu().numpy(), want_c[:P])
         assert torch.equal(g.matches[0], d_m)
+        # the same with the compact records written back to back (what the bench exchanges)
+        d_k = torch.zeros((P * cap, 3), dtype=torch.int16, device=dev)
+        d_off = torch.zeros(P + 1, dtype=torch.int64, device=dev)
+        ctx.match_pairs_compact_dev(capi.NORM_HAMMING, d_desc, F, rows * D, rows, None, D, d_pairs, P, 0.8, d_k,
+                                    P * cap, d_c, d_off)
+        gk = allpairs.PaddedGather(P, cap, 1, dev, compact=True)
+        gk.start(d_k, d_c)
+        gk.wait()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(gk.counts[0].cpu().numpy(), want_c[:P])
+        total = int(want_c[:P].sum())
+        assert _records(gk.matches[0][:total]).tobytes() == want[:total].tobytes()
     finally:
         dist.destroy_process_group()
 
