@@ -71,6 +71,7 @@ def hamming_roofline(prof, n_directions, rows, desc_bytes, launches_note):
             "traffic": None}
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, no sparsity
 
 KPS = 8192
 DESC_BYTES = 32
@@ -538,14 +539,24 @@ def run_c4(args, rank, world, local):
         ms, cnt = prof["l2_candidates_kernel"]
         avg_s = ms / cnt * 1e-3
         flop = 2.0 * nq * nt * dim
+        tf = flop / avg_s / 1e12
+        # The candidate pass runs on the bfloat16 matrix cores (every float split in two bf16
+        # halves, three products per term) unless SFM_L2_MFMA=f32 keeps it on the fp32 ones.
+        bf16 = not os.environ.get("SFM_L2_MFMA", "").startswith("f")
+        peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
+        roof = {"kernel": "l2_candidates_bf16_kernel" if bf16 else "l2_candidates_kernel",
+                "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(tf / peak, 4), "avg_launch_us": round(avg_s * 1e6, 2), "traffic": None,
+                "algorithmic_per_launch": f"2 x {nq} x {nt} x {dim} = {flop:.4g} FLOP"}
+        if bf16:
+            roof["issued"] = {"achieved": round(3 * tf, 2), "frac": round(3 * tf / peak, 4),
+                              "note": "three bf16 products per term of the dot product "
+                                      "(high*high, high*low, low*high)"}
+            roof["vs_fp32_matrix_peak"] = round(tf / MFMA_F32_PEAK_TFLOPS, 4)
         res[name] = {"ms_per_step": round(1e3 * dt / args.steps, 4),
                      "kernels": {k: kernel_line(prof, k) for k in sorted(prof)},
-                     "roofline": {"kernel": "l2_candidates_kernel", "bound": "mfma",
-                                  "achieved": round(flop / avg_s / 1e12, 2),
-                                  "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(flop / avg_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                                  "avg_launch_us": round(avg_s * 1e6, 2), "traffic": None,
-                                  "algorithmic_per_launch": f"2 x {nq} x {nt} x {dim} = {flop:.4g} FLOP"}}
+                     "exhaustive_queries_last_step": ctx.l2_exhaustive_count(),
+                     "roofline": roof}
         res[name]["_dt"] = dt
     main = res["unit_norm_real"]
     out = {
@@ -560,7 +571,7 @@ def run_c4(args, rank, world, local):
         "variants": {k: {kk: vv for kk, vv in v.items() if kk != "_dt"} for k, v in res.items()},
     }
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(
-        "c4", ["l2_candidates_kernel"])
+        "c4", [out["roofline"]["kernel"]])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle
 

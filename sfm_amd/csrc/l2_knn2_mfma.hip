@@ -317,6 +317,249 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
     }
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// -2 x of eight bfloat16 values (exact: a power of two; zeros stay zeros).
+__device__ __forceinline__ bf16x8 times_minus_two(bf16x8 v) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (__bf16)(-2.f * (float)v[e]);
+    return r;
+}
+
+// The candidate pass on the bfloat16 matrix cores (sixteen times the rate of the fp32 ones).
+// Every float x of the packed rows is split into xh + xl, two bfloat16 values that carry its
+// upper sixteen significant bits (l2_split_kernel), and q.t is formed as qh.th + qh.tl + ql.th
+// -- three v_mfma_f32_32x32x16_bf16 contractions with exact products and fp32 accumulation.
+// What is left out, ql.tl and the bits below xl, is below 4 * 2^-16 (||q||^2 + ||t||^2); the
+// re-score pass widens its error bound by that much, so the final result is still the exact
+// sequential one.  Layout, staging, start values and the fold are those of the fp32 kernel: a
+// split row is 2 K bfloat16 = K floats wide, upper halves first.
+template <int K, int NT>
+__global__ __launch_bounds__(kBlock) void l2_candidates_bf16_kernel(L2Args a) {
+    constexpr int kChunksPerRow = K / 4;             // 16-byte chunks of a split row
+    constexpr int kTileFloats = kTileRows * K;
+    constexpr int kQPerWave = 32 * NT;
+    constexpr int kQPerBlock = 4 * kQPerWave;
+    constexpr int kSteps = K / 16;                   // contraction steps of 16 dimensions
+    __shared__ __attribute__((aligned(16))) float lds[2 * kTileFloats + 2 * kTileRows];
+    float* norm_lds = lds + 2 * kTileFloats;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int g = blockIdx.x / a.blocks_per_group, inner = blockIdx.x % a.blocks_per_group;
+    const int per_dir = a.qtiles * a.splits;
+    const int dir = inner / per_dir;
+    const int qtile = (inner % per_dir) / a.splits;
+    const int split = inner % a.splits;
+    int qf = 0, tf = 0, problem = 0;
+    if (a.pairs) {
+        const int fa = a.pairs[2 * g], fb = a.pairs[2 * g + 1];
+        qf = dir ? fb : fa;
+        tf = dir ? fa : fb;
+        problem = 2 * g + dir;
+    }
+    const int nq = a.counts ? a.counts[qf] : a.nq_uniform;
+    const int nt = a.counts ? a.counts[tf] : a.nt_uniform;
+    const int q0 = qtile * kQPerBlock;
+    if (q0 >= nq) return;
+    const float* qrows = a.q_base + (size_t)qf * a.frame_floats;
+    const float* trows = a.t_base + (size_t)tf * a.frame_floats;
+    const float* tnorm = a.t_norms + (size_t)tf * a.rows_cap;
+
+    // B operand: this lane's query columns times -2, upper and lower halves, resident for the
+    // whole kernel.  Element [n][s] holds dimensions 16 s + 8 lh .. + 7 of query
+    // q0 + wave * kQPerWave + 32 n + li.
+    bf16x8 qh[NT][kSteps], ql[NT][kSteps];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int qi = q0 + wave * kQPerWave + 32 * n + li;
+        const bf16x8* src = reinterpret_cast<const bf16x8*>(qrows + (size_t)(qi < nq ? qi : 0) * K);
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) {
+            bf16x8 h = src[2 * s + lh], l = src[K / 8 + 2 * s + lh];
+            if (qi >= nq) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = l[e] = (__bf16)0.f;
+            }
+            qh[n][s] = times_minus_two(h);
+            ql[n][s] = times_minus_two(l);
+        }
+    }
+    float best0[NT], best1[NT], third[NT];
+    int bidx0[NT], bidx1[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        best0[n] = best1[n] = FLT_MAX;
+        third[n] = INFINITY;
+        bidx0[n] = bidx1[n] = -1;
+    }
+
+    const int chunk = (nt + a.splits - 1) / a.splits;
+    const int t_begin = split * chunk;
+    const int t_end = min(nt, t_begin + chunk);
+    const int ntiles = t_end > t_begin ? (t_end - t_begin + kTileRows - 1) / kTileRows : 0;
+
+    auto stage = [&](int k, int buf) {
+        const int tbase = t_begin + k * kTileRows;
+        float* dst = lds + buf * kTileFloats;
+#pragma unroll
+        for (int it = 0; it < kChunksPerRow / 4; ++it) {
+            const int instr = wave * (kChunksPerRow / 4) + it;
+            const int p = instr * 64 + lane;
+            const int row = p / kChunksPerRow, cpos = p % kChunksPerRow;
+            const int c = cpos ^ (row & 15);
+            int trow = tbase + row;
+            trow = trow < nt ? trow : nt - 1;  // clamped rows are masked by an infinite norm
+            glds16(trows + (size_t)trow * K + c * 4, dst + instr * 256);
+        }
+        if (tid < kTileRows) {
+            const int trow = tbase + tid;
+            norm_lds[buf * kTileRows + tid] = trow < t_end ? tnorm[trow] : INFINITY;
+        }
+    };
+
+    if (ntiles > 0) stage(0, 0);
+    __syncthreads();
+
+    floatx16 accA[2][NT], accB[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accA[mt][n][r] = accB[mt][n][r] = INFINITY;
+
+    // as in the fp32 kernel: strict comparisons, candidates in ascending train index
+    auto fold_key = [&](const floatx16 (&acc)[2][NT], int tbase, int kq) {
+        const int gi = kq / 4, r = kq % 4;
+        const int mt = gi / (NT * 4), n = (gi / 4) % NT, gq = gi % 4;
+        const float key = acc[mt][n][4 * gq + r];
+        const int ti = tbase + 32 * mt + 8 * gq + 4 * lh + r;
+        const unsigned long long c0 = __builtin_amdgcn_ballot_w64(key < best0[n]);
+        const unsigned long long c1 = __builtin_amdgcn_ballot_w64(key < best1[n]);
+        asm("v_med3_f32 %0, %0, %1, %2" : "+v"(third[n]) : "v"(key), "v"(best1[n]));
+        const float t = select_f(c1, key, best1[n]);
+        const int tix = select_i(c1, ti, bidx1[n]);
+        best1[n] = select_f(c0, best0[n], t);
+        bidx1[n] = select_i(c0, bidx0[n], tix);
+        best0[n] = select_f(c0, key, best0[n]);
+        bidx0[n] = select_i(c0, ti, bidx0[n]);
+    };
+
+    constexpr int kKeys = 2 * NT * 16;             // keys of a finished tile per lane
+    constexpr int kMfmas = kSteps * 2 * NT * 3;    // MFMAs of a tile per wave
+    auto tile_step = [&](floatx16 (&accC)[2][NT], const floatx16 (&accF)[2][NT], int k) {
+        const int buf = k & 1;
+        if (k + 1 < ntiles) stage(k + 1, buf ^ 1);
+        const float* tile = lds + buf * kTileFloats;
+        const float* nrm = norm_lds + buf * kTileRows;
+        const int tbase_prev = t_begin + (k - 1) * kTileRows;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            floatx16 init;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const floatx4 v = *reinterpret_cast<const floatx4*>(nrm + 32 * mt + 8 * gq + 4 * lh);
+                init[4 * gq + 0] = v.x;
+                init[4 * gq + 1] = v.y;
+                init[4 * gq + 2] = v.z;
+                init[4 * gq + 3] = v.w;
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) accC[mt][n] = init;
+        }
+        // fragments of step s: chunk 2 s + lh of the upper halves, the same chunk of the lower
+        // halves K / 8 chunks further on
+        auto load_a = [&](int s, bf16x8 (&ah)[2], bf16x8 (&al)[2]) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int row = 32 * mt + li;
+                const int ch = (2 * s + lh) ^ (row & 15), cl = (K / 8 + 2 * s + lh) ^ (row & 15);
+                ah[mt] = *reinterpret_cast<const bf16x8*>(tile + row * K + ch * 4);
+                al[mt] = *reinterpret_cast<const bf16x8*>(tile + row * K + cl * 4);
+            }
+        };
+        bf16x8 ah[2], al[2], ah_next[2], al_next[2];
+        load_a(0, ah, al);
+        // the fold of the finished tile is dealt over the MFMAs of this one, in a pinned order
+        // (see the fp32 kernel)
+        int unit = 0;
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) {
+            if (s + 1 < kSteps) load_a(s + 1, ah_next, al_next);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int term = 0; term < 3; ++term) {
+                        const bf16x8 av = term == 2 ? al[mt] : ah[mt];
+                        const bf16x8 bv = term == 1 ? ql[n][s] : qh[n][s];
+                        accC[mt][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, accC[mt][n], 0, 0, 0);
+#pragma unroll
+                        for (int kq = (unit * kKeys) / kMfmas; kq < ((unit + 1) * kKeys) / kMfmas; ++kq)
+                            fold_key(accF, tbase_prev, kq);
+                        ++unit;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                ah[mt] = ah_next[mt];
+                al[mt] = al_next[mt];
+            }
+        }
+        __syncthreads();
+    };
+
+    for (int k = 0; k < ntiles; k += 2) {
+        tile_step(accA, accB, k);
+        if (k + 1 < ntiles) tile_step(accB, accA, k + 1);
+    }
+    {
+        const int tbase_last = t_begin + (ntiles - 1) * kTileRows;
+        if (ntiles & 1) {
+#pragma unroll
+            for (int kq = 0; kq < kKeys; ++kq) fold_key(accA, tbase_last, kq);
+        } else if (ntiles > 0) {
+#pragma unroll
+            for (int kq = 0; kq < kKeys; ++kq) fold_key(accB, tbase_last, kq);
+        }
+    }
+
+    const size_t cbase = (((size_t)problem * a.splits + split) * a.rows_cap) * 4;
+    int32_t* cand = a.cand + cbase;
+    float* ckey = a.cand_key + cbase;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int qi = q0 + wave * kQPerWave + 32 * n + li;
+        if (qi < nq) {
+            cand[(size_t)qi * 4 + 2 * lh] = bidx0[n];
+            cand[(size_t)qi * 4 + 2 * lh + 1] = bidx1[n];
+            ckey[(size_t)qi * 4 + 2 * lh] = best0[n];
+            ckey[(size_t)qi * 4 + 2 * lh + 1] = best1[n];
+            a.cand_third[cbase / 2 + (size_t)qi * 2 + lh] = third[n];
+        }
+    }
+}
+
+// Packed rows of K floats -> rows of 2 K bfloat16: the K upper halves xh = bf16(x), then the K
+// lower halves xl = bf16(x - xh) (both round to nearest even; x - xh is exact in fp32).
+__global__ void l2_split_kernel(const float* __restrict__ src, size_t n_values, int K,
+                                __bf16* __restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_values;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / K;
+        const int j = (int)(i - row * K);
+        const float x = src[i];
+        const __bf16 h = (__bf16)x;
+        const __bf16 l = (__bf16)(x - (float)h);
+        dst[row * 2 * K + j] = h;
+        dst[row * 2 * K + K + j] = l;
+    }
+}
+
 // Zero-padded repack of float rows into rows of K floats, and ||row||^2.
 __global__ void l2_pack_kernel(const uint8_t* __restrict__ src, int n, size_t src_stride, int dim,
                                float* __restrict__ dst, int K, float* __restrict__ norms) {
@@ -368,6 +611,7 @@ struct RescoreArgs {
     const float* cand_third;
     const float* q_norms;  // ||q||^2 per packed row, rows_cap per frame
     const float* t_norm_max;  // largest ||t||^2 of any packed row (one float)
+    double key_error;  // bound on |ranking key + ||q||^2 - sequential distance| / (||q||^2 + max ||t||^2)
     int force_exhaustive;
     int32_t* knn_idx;  // [problem][rows_cap][2]
     float* knn_dist;
@@ -460,7 +704,8 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
     // norms (pairwise sums), of the K accumulation steps of the matrix pipe (each at most one
     // rounding of a partial sum <= ||t||^2 + 2 sum |q_j t_j| <= ||q||^2 + 2 ||t||^2) and of the
     // sequential sum itself (relative (K + 3) eps of a value <= 2 (||q||^2 + ||t||^2)); the
-    // factor below is more than twice their total.
+    // factor (4 K + 64) eps is more than twice their total.  The bfloat16 candidate pass has
+    // three times the accumulation steps and leaves out 4 * 2^-16 of the norms (see there).
     bool proven = true;
     if (others != ~0ull) {   // there are train rows outside the re-scored set
         if (k1 == ~0ull) {
@@ -470,7 +715,7 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
             const unsigned u = ord ^ ((ord >> 31) ? 0x80000000u : 0xFFFFFFFFu);
             const double T = (double)__uint_as_float(u);
             const double qn = (double)a.q_norms[(size_t)qf * a.rows_cap + q];
-            const double E = (4.0 * a.K + 64.0) * (double)FLT_EPSILON * (qn + (double)*a.t_norm_max);
+            const double E = a.key_error * (qn + (double)*a.t_norm_max);
             // NORM_L2 ranks by the rounded square root, which maps neighbouring sums to one
             // value: a row ties or wins only if its sum is below the square of the next float
             const float d1 = __uint_as_float((unsigned)(k1 >> 32));
@@ -610,10 +855,32 @@ int make_l2_plan(const sfm_ctx* ctx, int dim, int nq_max, int nt_max, int n_prob
 }
 
 template <int K, int NT>
-int launch_candidates(sfm_ctx* ctx, const L2Args& a, long grid) {
+int launch_candidates(sfm_ctx* ctx, const L2Args& a, long grid, bool bf16) {
     KernelTimer timer(ctx, KID_L2_CANDIDATES);
-    hipLaunchKernelGGL((l2_candidates_kernel<K, NT>), dim3((unsigned)grid), dim3(kBlock), 0,
-                       ctx->stream, a);
+    if (bf16)
+        hipLaunchKernelGGL((l2_candidates_bf16_kernel<K, NT>), dim3((unsigned)grid), dim3(kBlock), 0,
+                           ctx->stream, a);
+    else
+        hipLaunchKernelGGL((l2_candidates_kernel<K, NT>), dim3((unsigned)grid), dim3(kBlock), 0,
+                           ctx->stream, a);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+// SFM_L2_MFMA=f32 keeps the candidate pass on the fp32 matrix cores (a measuring aid, read per
+// call); the default is the bfloat16 split.
+bool l2_use_bf16() {
+    const char* e = getenv("SFM_L2_MFMA");
+    return !(e && e[0] == 'f');
+}
+
+// Split copies of packed rows (n_values floats) for the bfloat16 candidate pass.
+int l2_split(sfm_ctx* ctx, const float* packed, size_t n_values, int K, float* split) {
+    if (n_values == 0) return SFM_OK;
+    KernelTimer timer(ctx, KID_L2_PACK);
+    const unsigned blocks = (unsigned)std::min<size_t>((n_values + 255) / 256, 8192);
+    hipLaunchKernelGGL(l2_split_kernel, dim3(blocks), dim3(256), 0, ctx->stream, packed, n_values, K,
+                       reinterpret_cast<__bf16*>(split));
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
 }
@@ -650,7 +917,7 @@ bool l2_force_exhaustive() {
 // [problem][rows_cap][2].  norms: ||row||^2 of every packed row (n_norms of them, rows_cap per
 // frame), used for the queries' norms and, through its maximum, for the error bound.
 int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const float* q_base,
-                  const float* t_base, const float* q_norms, const float* t_norms, size_t n_t_norms,
+                  const float* t_base, const float* q_split, const float* t_split, const float* q_norms, const float* t_norms, size_t n_t_norms,
                   size_t frame_floats, int rows_cap, const int32_t* d_counts, int nq_uniform, int nt_uniform,
                   const int32_t* d_pairs, int n_problems, const L2Scratch& s) {
     L2Args a{};
@@ -681,12 +948,18 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
                            s.norm_max);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
+    // q_split / t_split: the rows split into bfloat16 halves (same row pitch), or null
+    const bool bf16 = q_split && t_split;
+    if (bf16) {
+        a.q_base = q_split;
+        a.t_base = t_split;
+    }
     if (plan.K == 64)
-        SFM_RETURN_IF((launch_candidates<64, 2>(ctx, a, grid)));
+        SFM_RETURN_IF((launch_candidates<64, 2>(ctx, a, grid, bf16)));
     else if (plan.K == 128)
-        SFM_RETURN_IF((launch_candidates<128, 2>(ctx, a, grid)));
+        SFM_RETURN_IF((launch_candidates<128, 2>(ctx, a, grid, bf16)));
     else
-        SFM_RETURN_IF((launch_candidates<256, 1>(ctx, a, grid)));
+        SFM_RETURN_IF((launch_candidates<256, 1>(ctx, a, grid, bf16)));
 
     RescoreArgs r{};
     r.q_base = q_base;
@@ -706,6 +979,8 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     r.cand_third = s.cand_third;
     r.q_norms = q_norms;
     r.t_norm_max = s.norm_max;
+    r.key_error = bf16 ? (12.0 * plan.K + 64.0) * (double)FLT_EPSILON + 4.0 / 65536.0
+                       : (4.0 * plan.K + 64.0) * (double)FLT_EPSILON;
     r.force_exhaustive = l2_force_exhaustive() ? 1 : 0;
     r.knn_idx = s.knn_idx;
     r.knn_dist = s.knn_dist;
@@ -756,6 +1031,8 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
     sz.take<float>((size_t)(nt > 0 ? nt : 1) * K);
     sz.take<float>((size_t)rows_cap);
     sz.take<float>((size_t)rows_cap);
+    sz.take<float>((size_t)nq * K);
+    sz.take<float>((size_t)(nt > 0 ? nt : 1) * K);
     l2_scratch_carve(sz, plan, rows_cap, 1, &sc);
     void* ws;
     SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
@@ -764,12 +1041,19 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
     float* tp = c.take<float>((size_t)(nt > 0 ? nt : 1) * K);
     float* qn = c.take<float>((size_t)rows_cap);
     float* tn = c.take<float>((size_t)rows_cap);
+    float* qs = c.take<float>((size_t)nq * K);
+    float* ts = c.take<float>((size_t)(nt > 0 ? nt : 1) * K);
     l2_scratch_carve(c, plan, rows_cap, 1, &sc);
     SFM_HIP_CHECK(ctx, hipMemsetAsync(ctx->stats, 0, sizeof(int32_t), ctx->stream));
     SFM_RETURN_IF(l2_pack(ctx, d_q, nq, q_stride, dim, qp, K, qn));
     SFM_RETURN_IF(l2_pack(ctx, d_t, nt, t_stride, dim, tp, K, tn));
-    SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, qp, tp, qn, tn, (size_t)nt, 0, rows_cap, nullptr, nq,
-                                nt, nullptr, 1, sc));
+    const bool bf16 = l2_use_bf16();
+    if (bf16) {
+        SFM_RETURN_IF(l2_split(ctx, qp, (size_t)nq * K, K, qs));
+        SFM_RETURN_IF(l2_split(ctx, tp, (size_t)nt * K, K, ts));
+    }
+    SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, qp, tp, bf16 ? qs : nullptr, bf16 ? ts : nullptr, qn, tn,
+                                (size_t)nt, 0, rows_cap, nullptr, nq, nt, nullptr, 1, sc));
     SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, sc.knn_idx, sizeof(int32_t) * 2 * nq, hipMemcpyDeviceToDevice,
                                       ctx->stream));
     SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_dist, sc.knn_dist, sizeof(float) * 2 * nq, hipMemcpyDeviceToDevice,
@@ -780,6 +1064,7 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
 namespace {
 struct L2PairBuffers {
     float* packed;
+    float* split;
     float* norms;
     L2Scratch sc;
     int32_t* best;
@@ -788,6 +1073,7 @@ struct L2PairBuffers {
 void l2_pairs_carve(Carver& c, const L2Plan& plan, int n_frames, int rows, int n_pairs,
                     L2PairBuffers* b) {
     b->packed = c.take<float>((size_t)n_frames * rows * plan.K);
+    b->split = c.take<float>((size_t)n_frames * rows * plan.K);
     b->norms = c.take<float>((size_t)n_frames * rows);
     const size_t nprob = 2 * (size_t)n_pairs;
     l2_scratch_carve(c, plan, rows, nprob, &b->sc);
@@ -833,10 +1119,13 @@ int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_fr
                               rows_per_frame, (size_t)dim * 4, dim,
                               b.packed + (size_t)f * rows_per_frame * plan.K, plan.K,
                               b.norms + (size_t)f * rows_per_frame));
+    const bool bf16 = l2_use_bf16();
+    if (bf16) SFM_RETURN_IF(l2_split(ctx, b.packed, (size_t)n_frames * rows_per_frame * plan.K, plan.K, b.split));
+    const float* split = bf16 ? b.split : nullptr;
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
         const int np = chunk < n_pairs - p0 ? chunk : n_pairs - p0;
         const int32_t* pairs = d_pairs + 2 * (size_t)p0;
-        SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, b.packed, b.packed, b.norms, b.norms,
+        SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, b.packed, b.packed, split, split, b.norms, b.norms,
                                     (size_t)n_frames * rows_per_frame, (size_t)rows_per_frame * plan.K,
                                     rows_per_frame, d_counts, rows_per_frame, rows_per_frame, pairs, 2 * np,
                                     b.sc));
