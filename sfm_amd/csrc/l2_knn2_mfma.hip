@@ -319,28 +319,25 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// -2 x of eight bfloat16 values (exact: a power of two; zeros stay zeros).
-__device__ __forceinline__ bf16x8 times_minus_two(bf16x8 v) {
-    bf16x8 r;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = (__bf16)(-2.f * (float)v[e]);
-    return r;
-}
-
 // The candidate pass on the bfloat16 matrix cores (sixteen times the rate of the fp32 ones).
 // Every float x of the packed rows is split into xh + xl, two bfloat16 values that carry its
 // upper sixteen significant bits (l2_split_kernel), and q.t is formed as qh.th + qh.tl + ql.th
 // -- three v_mfma_f32_32x32x16_bf16 contractions with exact products and fp32 accumulation.
 // What is left out, ql.tl and the bits below xl, is below 4 * 2^-16 (||q||^2 + ||t||^2); the
 // re-score pass widens its error bound by that much, so the final result is still the exact
-// sequential one.  Layout, staging, start values and the fold are those of the fp32 kernel: a
-// split row is 2 K bfloat16 = K floats wide, upper halves first.
-template <int K, int NT>
-__global__ __launch_bounds__(kBlock) void l2_candidates_bf16_kernel(L2Args a) {
+// sequential one.  Layout and staging are those of the fp32 kernel: a split row is 2 K bfloat16
+// = K floats wide, upper halves first.  A wave owns one 32-query column block (NT = 1) so that
+// two waves fit a SIMD: one wave issues a vector instruction every six cycles at best, two
+// interleave, and the fold -- four instructions per key -- runs underneath the matrix
+// instructions of the next tile.  (With 64 queries per wave and one wave per SIMD the same fold
+// left the matrix pipe idle half of the time.)
+template <int K, int NT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void l2_candidates_bf16_kernel(L2Args a) {
     constexpr int kChunksPerRow = K / 4;             // 16-byte chunks of a split row
     constexpr int kTileFloats = kTileRows * K;
     constexpr int kQPerWave = 32 * NT;
-    constexpr int kQPerBlock = 4 * kQPerWave;
+    constexpr int kQPerBlock = WAVES * kQPerWave;
+    static_assert(kChunksPerRow % WAVES == 0, "the waves share the staging of a tile evenly");
     constexpr int kSteps = K / 16;                   // contraction steps of 16 dimensions
     __shared__ __attribute__((aligned(16))) float lds[2 * kTileFloats + 2 * kTileRows];
     float* norm_lds = lds + 2 * kTileFloats;
@@ -368,8 +365,8 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_bf16_kernel(L2Args a) {
     const float* trows = a.t_base + (size_t)tf * a.frame_floats;
     const float* tnorm = a.t_norms + (size_t)tf * a.rows_cap;
 
-    // B operand: this lane's query columns times -2, upper and lower halves, resident for the
-    // whole kernel.  Element [n][s] holds dimensions 16 s + 8 lh .. + 7 of query
+    // B operand: this lane's query columns, upper and lower halves, resident for the whole
+    // kernel.  Element [n][s] holds dimensions 16 s + 8 lh .. + 7 of query
     // q0 + wave * kQPerWave + 32 n + li.
     bf16x8 qh[NT][kSteps], ql[NT][kSteps];
 #pragma unroll
@@ -383,15 +380,23 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_bf16_kernel(L2Args a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) h[e] = l[e] = (__bf16)0.f;
             }
-            qh[n][s] = times_minus_two(h);
-            ql[n][s] = times_minus_two(l);
+            qh[n][s] = h;
+            ql[n][s] = l;
         }
     }
+    // The matrix pipe accumulates q.t - ||t||^2 / 2, the ranking key ||t||^2 - 2 q.t times -1/2
+    // (an exact scaling, so the key is the one the fp32 kernel forms): the largest accumulators
+    // are the nearest rows, and neither operand needs a factor.
+    // Running best two keys of each query column with their train rows, and the third-smallest
+    // key seen.  kNoRow = 2^127, huge, finite and with clear low mantissa bits, stands for "no
+    // row": a key keeps a position tag in those bits (below), which an infinity cannot carry.
+    const float kNoRow = __uint_as_float(0x7F000000u);
+    const float kNoRowAcc = -0.5f * kNoRow;
     float best0[NT], best1[NT], third[NT];
     int bidx0[NT], bidx1[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        best0[n] = best1[n] = FLT_MAX;
+        best0[n] = best1[n] = kNoRow;
         third[n] = INFINITY;
         bidx0[n] = bidx1[n] = -1;
     }
@@ -405,18 +410,20 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_bf16_kernel(L2Args a) {
         const int tbase = t_begin + k * kTileRows;
         float* dst = lds + buf * kTileFloats;
 #pragma unroll
-        for (int it = 0; it < kChunksPerRow / 4; ++it) {
-            const int instr = wave * (kChunksPerRow / 4) + it;
+        for (int it = 0; it < kChunksPerRow / WAVES; ++it) {
+            const int instr = wave * (kChunksPerRow / WAVES) + it;
             const int p = instr * 64 + lane;
             const int row = p / kChunksPerRow, cpos = p % kChunksPerRow;
             const int c = cpos ^ (row & 15);
             int trow = tbase + row;
-            trow = trow < nt ? trow : nt - 1;  // clamped rows are masked by an infinite norm
+            trow = trow < nt ? trow : nt - 1;  // clamped rows are masked by a norm of kNoRow
             glds16(trows + (size_t)trow * K + c * 4, dst + instr * 256);
         }
         if (tid < kTileRows) {
             const int trow = tbase + tid;
-            norm_lds[buf * kTileRows + tid] = trow < t_end ? tnorm[trow] : INFINITY;
+            // q.t changes nothing in kNoRowAcc (its ulp is 2^103): a masked row's key is never
+            // below a best
+            norm_lds[buf * kTileRows + tid] = trow < t_end ? -0.5f * tnorm[trow] : kNoRowAcc;
         }
     };
 
@@ -429,17 +436,37 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_bf16_kernel(L2Args a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) accA[mt][n][r] = accB[mt][n][r] = INFINITY;
+            for (int r = 0; r < 16; ++r) accA[mt][n][r] = accB[mt][n][r] = kNoRowAcc;
 
-    // as in the fp32 kernel: strict comparisons, candidates in ascending train index
-    auto fold_key = [&](const floatx16 (&acc)[2][NT], int tbase, int kq) {
+    // The fold of a finished tile.  A lane holds 32 accumulators of each of its query columns;
+    // the five low mantissa bits of one are replaced by its position among them (a change
+    // below 2^-18 of its size, which the error bound of the re-score pass covers), so that the
+    // three largest of the tile fall out of one maximum and two medians each with no train
+    // index carried along -- the tagged values of a tile are all different.  Only the largest
+    // two then enter the running lists, as keys, with the train row their tags name.
+    float top0[NT], top1[NT], top2[NT];
+    auto fold_key = [&](const floatx16 (&acc)[2][NT], int kq) {
         const int gi = kq / 4, r = kq % 4;
         const int mt = gi / (NT * 4), n = (gi / 4) % NT, gq = gi % 4;
-        const float key = acc[mt][n][4 * gq + r];
-        const int ti = tbase + 32 * mt + 8 * gq + 4 * lh + r;
+        const unsigned tag = 16 * mt + 4 * gq + r;
+        const float v =
+            __uint_as_float((__float_as_uint(acc[mt][n][4 * gq + r]) & ~31u) | tag);
+        asm("v_med3_f32 %0, %0, %1, %2" : "+v"(top2[n]) : "v"(v), "v"(top1[n]));
+        asm("v_med3_f32 %0, %0, %1, %2" : "+v"(top1[n]) : "v"(v), "v"(top0[n]));
+        asm("v_max_f32 %0, %0, %1" : "+v"(top0[n]) : "v"(v));
+    };
+    // which = 0, 1: the largest, second-largest accumulator of the tile enters the lists of
+    // column n as a key (strict comparisons: of equal keys the earlier tile stays ahead);
+    // which = 2: the third only moves the third-smallest key seen.
+    auto merge = [&](int n, int which, int tbase) {
+        const float v = which == 0 ? top0[n] : which == 1 ? top1[n] : top2[n];
+        const float key = -2.f * v;   // exact
+        asm("v_med3_f32 %0, %0, %1, %2" : "+v"(third[n]) : "v"(key), "v"(best1[n]));
+        if (which == 2) return;
+        const unsigned tag = __float_as_uint(v);
+        const int ti = tbase + 4 * lh + (int)(((tag & 28u) << 1) | (tag & 3u));
         const unsigned long long c0 = __builtin_amdgcn_ballot_w64(key < best0[n]);
         const unsigned long long c1 = __builtin_amdgcn_ballot_w64(key < best1[n]);
-        asm("v_med3_f32 %0, %0, %1, %2" : "+v"(third[n]) : "v"(key), "v"(best1[n]));
         const float t = select_f(c1, key, best1[n]);
         const int tix = select_i(c1, ti, bidx1[n]);
         best1[n] = select_f(c0, best0[n], t);
@@ -447,9 +474,15 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_bf16_kernel(L2Args a) {
         best0[n] = select_f(c0, key, best0[n]);
         bidx0[n] = select_i(c0, ti, bidx0[n]);
     };
+    auto reset_tops = [&]() {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) top0[n] = top1[n] = top2[n] = -INFINITY;
+    };
 
     constexpr int kKeys = 2 * NT * 16;             // keys of a finished tile per lane
     constexpr int kMfmas = kSteps * 2 * NT * 3;    // MFMAs of a tile per wave
+    constexpr int kFoldUnits = kMfmas - 3 * NT;    // the last 3 NT carry the merges
+    static_assert(kFoldUnits > 0, "the fold needs room beside the merges");
     auto tile_step = [&](floatx16 (&accC)[2][NT], const floatx16 (&accF)[2][NT], int k) {
         const int buf = k & 1;
         if (k + 1 < ntiles) stage(k + 1, buf ^ 1);
@@ -485,22 +518,29 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_bf16_kernel(L2Args a) {
         load_a(0, ah, al);
         // the fold of the finished tile is dealt over the MFMAs of this one, in a pinned order
         // (see the fp32 kernel)
+        reset_tops();
         int unit = 0;
 #pragma unroll
         for (int s = 0; s < kSteps; ++s) {
             if (s + 1 < kSteps) load_a(s + 1, ah_next, al_next);
+            // the three products of one accumulator are 2 NT MFMAs apart: none waits for the
+            // one before it, and the fold issues underneath them
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int term = 0; term < 3; ++term)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int term = 0; term < 3; ++term) {
+                    for (int n = 0; n < NT; ++n) {
                         const bf16x8 av = term == 2 ? al[mt] : ah[mt];
                         const bf16x8 bv = term == 1 ? ql[n][s] : qh[n][s];
                         accC[mt][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, accC[mt][n], 0, 0, 0);
+                        if (unit < kFoldUnits) {
 #pragma unroll
-                        for (int kq = (unit * kKeys) / kMfmas; kq < ((unit + 1) * kKeys) / kMfmas; ++kq)
-                            fold_key(accF, tbase_prev, kq);
+                            for (int kq = (unit * kKeys) / kFoldUnits; kq < ((unit + 1) * kKeys) / kFoldUnits; ++kq)
+                                fold_key(accF, kq);
+                        } else {
+                            merge((unit - kFoldUnits) / 3, (unit - kFoldUnits) % 3, tbase_prev);
+                        }
                         ++unit;
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -519,13 +559,16 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_bf16_kernel(L2Args a) {
     }
     {
         const int tbase_last = t_begin + (ntiles - 1) * kTileRows;
+        reset_tops();
         if (ntiles & 1) {
 #pragma unroll
-            for (int kq = 0; kq < kKeys; ++kq) fold_key(accA, tbase_last, kq);
+            for (int kq = 0; kq < kKeys; ++kq) fold_key(accA, kq);
         } else if (ntiles > 0) {
 #pragma unroll
-            for (int kq = 0; kq < kKeys; ++kq) fold_key(accB, tbase_last, kq);
+            for (int kq = 0; kq < kKeys; ++kq) fold_key(accB, kq);
         }
+#pragma unroll
+        for (int u = 0; u < 3 * NT; ++u) merge(u / 3, u % 3, tbase_last);
     }
 
     const size_t cbase = (((size_t)problem * a.splits + split) * a.rows_cap) * 4;
@@ -857,9 +900,9 @@ int make_l2_plan(const sfm_ctx* ctx, int dim, int nq_max, int nt_max, int n_prob
 template <int K, int NT>
 int launch_candidates(sfm_ctx* ctx, const L2Args& a, long grid, bool bf16) {
     KernelTimer timer(ctx, KID_L2_CANDIDATES);
-    if (bf16)
-        hipLaunchKernelGGL((l2_candidates_bf16_kernel<K, NT>), dim3((unsigned)grid), dim3(kBlock), 0,
-                           ctx->stream, a);
+    if (bf16)   // the same queries per workgroup, one 32-query column block per wave
+        hipLaunchKernelGGL((l2_candidates_bf16_kernel<K, 1, 4 * NT>), dim3((unsigned)grid),
+                           dim3(64 * 4 * NT), 0, ctx->stream, a);
     else
         hipLaunchKernelGGL((l2_candidates_kernel<K, NT>), dim3((unsigned)grid), dim3(kBlock), 0,
                            ctx->stream, a);
@@ -979,7 +1022,10 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     r.cand_third = s.cand_third;
     r.q_norms = q_norms;
     r.t_norm_max = s.norm_max;
-    r.key_error = bf16 ? (12.0 * plan.K + 64.0) * (double)FLT_EPSILON + 4.0 / 65536.0
+    // bfloat16 pass: three times the accumulation steps, 4 * 2^-16 of the norms left out by the
+    // split, and the position tag in a key's five low bits (below 2^-18 of a key that is at
+    // most twice the norms: 2^-17, counted as 2^-16)
+    r.key_error = bf16 ? (12.0 * plan.K + 64.0) * (double)FLT_EPSILON + 5.0 / 65536.0
                        : (4.0 * plan.K + 64.0) * (double)FLT_EPSILON;
     r.force_exhaustive = l2_force_exhaustive() ? 1 : 0;
     r.knn_idx = s.knn_idx;
