@@ -587,37 +587,86 @@ __global__ __launch_bounds__(64 * WAVES) void l2_candidates_bf16_kernel(L2Args a
     }
 }
 
-// Packed rows of K floats -> rows of 2 K bfloat16: the K upper halves xh = bf16(x), then the K
-// lower halves xl = bf16(x - xh) (both round to nearest even; x - xh is exact in fp32).
-__global__ void l2_split_kernel(const float* __restrict__ src, size_t n_values, int K,
-                                __bf16* __restrict__ dst) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_values;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const size_t row = i / K;
-        const int j = (int)(i - row * K);
-        const float x = src[i];
-        const __bf16 h = (__bf16)x;
-        const __bf16 l = (__bf16)(x - (float)h);
-        dst[row * 2 * K + j] = h;
-        dst[row * 2 * K + K + j] = l;
-    }
-}
+// Up to two sets of float rows (queries and train rows, or the frames of a sequence) are brought
+// into the layout of the passes in one launch: zero-padded rows of K floats, ||row||^2, the rows
+// split into 2 K bfloat16 -- the K upper halves xh = bf16(x), then the K lower halves
+// xl = bf16(x - xh), both rounded to nearest even (x - xh is exact in fp32) -- and the largest
+// norm of a set (norm_max must be zero before the launch; non-negative floats order like their
+// bit patterns; a NaN norm is skipped, its row never ranks anyway).
+struct PackSet {
+    const uint8_t* src;
+    int rows, rows_per_group;          // row r lies in group r / rows_per_group
+    size_t group_stride, row_stride;   // bytes
+    float* dst;                        // [rows][K]
+    __bf16* split;                     // [rows][2 K], or null
+    float* norms;                      // [rows]
+    float* norm_max;                   // one float, or null
+};
+struct PackArgs {
+    PackSet set[2];
+    int blocks0;   // workgroups of set 0; the rest serve set 1
+    int dim, K;
+};
+constexpr int kPackRowsPerWave = 8;
 
-// Zero-padded repack of float rows into rows of K floats, and ||row||^2.
-__global__ void l2_pack_kernel(const uint8_t* __restrict__ src, int n, size_t src_stride, int dim,
-                               float* __restrict__ dst, int K, float* __restrict__ norms) {
-    const int row = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+__global__ __launch_bounds__(kBlock) void l2_pack_kernel(PackArgs a) {
+    const bool second = (int)blockIdx.x >= a.blocks0;
+    const PackSet& p = a.set[second ? 1 : 0];
+    const int block = second ? blockIdx.x - a.blocks0 : blockIdx.x;
     const int lane = threadIdx.x & 63;
-    if (row >= n) return;
-    const float* s = reinterpret_cast<const float*>(src + (size_t)row * src_stride);
-    float acc = 0.f;
-    for (int j = lane; j < K; j += 64) {
-        const float v = j < dim ? s[j] : 0.f;
-        if (dst) dst[(size_t)row * K + j] = v;
-        acc += v * v;
+    const int row0 = (block * (kBlock / 64) + (threadIdx.x >> 6)) * kPackRowsPerWave;
+    const int K = a.K;
+    // A lane takes element pairs lane and lane + 64 of a row (K <= 256: at most 128 pairs).  All
+    // the loads of the wave's rows go out before the first value is used.
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    floatx2 v[kPackRowsPerWave][2];
+#pragma unroll
+    for (int r = 0; r < kPackRowsPerWave; ++r) {
+        const int row = min(row0 + r, p.rows - 1);
+        const int group = row / p.rows_per_group;
+        const float* s = reinterpret_cast<const float*>(p.src + (size_t)group * p.group_stride +
+                                                        (size_t)(row - group * p.rows_per_group) * p.row_stride);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = 2 * (lane + 64 * i);
+            v[r][i].x = j < a.dim ? s[j] : 0.f;
+            v[r][i].y = j + 1 < a.dim ? s[j + 1] : 0.f;
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) norms[row] = acc;
+    float largest = 0.f;
+#pragma unroll
+    for (int r = 0; r < kPackRowsPerWave; ++r) {
+        const int row = row0 + r;
+        if (row >= p.rows) break;   // wave-uniform
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = 2 * (lane + 64 * i);
+            if (j < K) {
+                const floatx2 x = v[r][i];
+                *reinterpret_cast<floatx2*>(p.dst + (size_t)row * K + j) = x;
+                if (p.split) {
+                    bf16x2 h, l;
+                    h.x = (__bf16)x.x;
+                    h.y = (__bf16)x.y;
+                    l.x = (__bf16)(x.x - (float)h.x);
+                    l.y = (__bf16)(x.y - (float)h.y);
+                    *reinterpret_cast<bf16x2*>(p.split + (size_t)row * 2 * K + j) = h;
+                    *reinterpret_cast<bf16x2*>(p.split + (size_t)row * 2 * K + K + j) = l;
+                }
+                acc += x.x * x.x;
+                acc += x.y * x.y;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) p.norms[row] = acc;
+        largest = acc > largest ? acc : largest;
+    }
+    // the maximum only grows: a wave whose rows do not exceed what is there leaves it alone
+    // (thousands of atomics on one address would take longer than the packing)
+    if (p.norm_max && lane == 0 && largest > *reinterpret_cast<volatile float*>(p.norm_max))
+        atomicMax(reinterpret_cast<unsigned*>(p.norm_max), __float_as_uint(largest));
 }
 
 // Squared distance as the sequential float sum d += (a-b)*(a-b), the scalar order of OpenCV's
@@ -663,13 +712,44 @@ struct RescoreArgs {
     int32_t* stat_exhaustive;  // per-context total of such queries since the entry point began
 };
 
+// min(v, v of the lane the DPP control names); a lane the control leaves out keeps its own
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    const unsigned olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const unsigned ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o < v ? o : v;
+}
+
+// Smallest v of the wave, in every lane.  Data-parallel-primitive moves in the vector ALU: a
+// dozen of these per query through ds_bpermute kept the LDS pipe of a CU busy longer than the
+// rest of the re-score kernel takes.
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(v, o);
-        v = other < v ? other : v;
-    }
-    return v;
+    v = dpp_min_u64<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_min_u64<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_min_u64<0x141, 0xf>(v);   // row_half_mirror
+    v = dpp_min_u64<0x140, 0xf>(v);   // row_mirror: every lane of a row of 16 holds the row's
+    v = dpp_min_u64<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
+    v = dpp_min_u64<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3: lane 63 holds the wave's
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, 63);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_min_u32(unsigned v) {
+    const unsigned o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {   // same moves as wave_min_u64
+    v = dpp_min_u32<0xB1, 0xf>(v);
+    v = dpp_min_u32<0x4E, 0xf>(v);
+    v = dpp_min_u32<0x141, 0xf>(v);
+    v = dpp_min_u32<0x140, 0xf>(v);
+    v = dpp_min_u32<0x142, 0xa>(v);
+    v = dpp_min_u32<0x143, 0xc>(v);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 constexpr int kRescored = 8;  // candidates per query whose distance is recomputed
@@ -679,7 +759,17 @@ constexpr int kRescored = 8;  // candidates per query whose distance is recomput
 // cannot be among the two nearest unless more than kRescored - 2 candidates lie within the
 // rounding of the MFMA form of the second-best distance.  (Re-scoring all of them gathered
 // 64 train rows per query: 655 MB for 20 000 queries, most of this kernel's time.)
+//
+// The squared differences of a re-scored row are formed by the whole wave -- lane l takes
+// elements KPL l .. KPL l + KPL - 1 of the row (one coalesced load), the loads of all the rows
+// in flight together -- and parked in LDS; the lane that owns the candidate then adds them up
+// in element order.  KPL = K / 64.
+template <int KPL>
 __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
+    constexpr int K = 64 * KPL;
+    constexpr int kPitch = K + 4;   // the owners' 16-byte reads fall in different banks
+    __shared__ __attribute__((aligned(16))) float s_terms[kBlock / 64][kRescored * kPitch];
+    typedef float rowslice __attribute__((ext_vector_type(KPL)));
     const int lane = threadIdx.x & 63;
     const int problem = blockIdx.y;
     const int q = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -692,11 +782,14 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
     }
     const int nq = a.counts ? a.counts[qf] : a.nq_uniform;
     if (q >= nq) return;  // wave-uniform
-    const float* qrow = a.q_base + (size_t)qf * a.frame_floats + (size_t)q * a.K;
+    const float* qrow = a.q_base + (size_t)qf * a.frame_floats + (size_t)q * K;
     const float* trows = a.t_base + (size_t)tf * a.frame_floats;
     const int ncand = a.splits * 4;
+    // A candidate's ranking key in orderable form, its six low bits replaced by the lane that
+    // holds it: all different, so the smallest kRescored are well defined, and within 2^-17 of
+    // the key (the error bound of the proof allows for it).
     int ti = -1;
-    unsigned long long pre = ~0ull;  // (orderable ranking key, train index)
+    unsigned pre = 0xFFFFFFFFu;
     if (lane < ncand) {
         const int split = lane >> 2, slot = lane & 3;
         const size_t o = ((((size_t)problem * a.splits + split) * a.rows_cap) + q) * 4 + slot;
@@ -704,41 +797,80 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
         if (ti >= 0) {
             const unsigned u = __float_as_uint(a.cand_key[o]);
             const unsigned ord = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-            pre = ((unsigned long long)ord << 32) | (unsigned)ti;
+            pre = (ord & ~63u) | (unsigned)lane;
         }
     }
     bool chosen = ncand <= kRescored;
-    unsigned long long ninth = ~0ull;  // smallest (key, index) among the candidates not re-scored
+    unsigned ninth = 0xFFFFFFFFu;  // smallest key among the candidates not re-scored
     if (!chosen) {
-        unsigned long long rest = pre;
+        unsigned rest = pre;
 #pragma unroll 1
         for (int r = 0; r < kRescored; ++r) {
-            const unsigned long long m = wave_min_u64(rest);
-            if (m == ~0ull) break;  // wave-uniform
+            const unsigned m = wave_min_u32(rest);
+            if (m == 0xFFFFFFFFu) break;  // wave-uniform
             if (rest == m) {
                 chosen = true;
-                rest = ~0ull;
+                rest = 0xFFFFFFFFu;
             }
         }
-        ninth = wave_min_u64(rest);
+        ninth = wave_min_u32(rest);
     }
     if (!chosen) ti = -1;
     // T: no train row outside the re-scored set has a smaller ranking key (orderable form)
-    unsigned long long others = ninth;
+    unsigned others = ninth;
     if (lane < 2 * a.splits) {
         const int split = lane >> 1, half = lane & 1;
         const float k3 = a.cand_third[((((size_t)problem * a.splits + split) * a.rows_cap) + q) * 2 + half];
         const unsigned u = __float_as_uint(k3);
         const unsigned ord = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-        const unsigned long long v = ((unsigned long long)ord << 32) | 0xFFFFFFFFu;
-        others = v < others ? v : others;
+        others = ord < others ? ord : others;
     }
-    others = wave_min_u64(others);
+    others = wave_min_u32(others);
+    // the rows to re-score, dealt to lanes 0 .. kRescored - 1 in lane order of their holders
+    unsigned long long holders = __builtin_amdgcn_ballot_w64(ti >= 0);
+    int row_of[kRescored];
+#pragma unroll
+    for (int c = 0; c < kRescored; ++c) {
+        row_of[c] = -1;
+        if (holders) {   // wave-uniform
+            row_of[c] = __builtin_amdgcn_readlane(ti, __builtin_ctzll(holders));
+            holders &= holders - 1;
+        }
+    }
+    float* terms = s_terms[threadIdx.x >> 6];
+    {
+        const rowslice qv = *reinterpret_cast<const rowslice*>(qrow + KPL * lane);
+        rowslice tv[kRescored];
+#pragma unroll
+        for (int c = 0; c < kRescored; ++c)   // an absent row reads row 0 and is ignored
+            tv[c] = *reinterpret_cast<const rowslice*>(trows + (size_t)(row_of[c] < 0 ? 0 : row_of[c]) * K +
+                                                       KPL * lane);
+#pragma unroll
+        for (int c = 0; c < kRescored; ++c) {
+            const rowslice v = qv - tv[c];
+            *reinterpret_cast<rowslice*>(terms + c * kPitch + KPL * lane) = v * v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();   // LDS serves a wave in order: the sums below see the terms
+    int mine = -1;
+#pragma unroll
+    for (int c = 0; c < kRescored; ++c) mine = lane == c ? row_of[c] : mine;
     unsigned long long key = ~0ull;   // (distance, train index)
-    if (ti >= 0) {
-        float d = sequential_sqr(qrow, trows + (size_t)ti * a.K, a.K);
+    if (mine >= 0) {
+        // d += (a-b)*(a-b) in element order, the scalar order of OpenCV's normL2Sqr (rows are
+        // zero-padded to K floats and (0 - 0)^2 adds an exact zero)
+        const floatx4* t4 = reinterpret_cast<const floatx4*>(terms + lane * kPitch);
+        float d = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < K / 4; ++j) {
+            const floatx4 v = t4[j];
+            d += v.x;
+            d += v.y;
+            d += v.z;
+            d += v.w;
+        }
         if (!a.squared) d = sqrtf(d);  // batchDistL2_32f
-        key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)ti;
+        key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)mine;
     }
     const unsigned long long k0 = wave_min_u64(key);
     const unsigned long long k1 = wave_min_u64(key == k0 ? ~0ull : key);
@@ -750,11 +882,11 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
     // factor (4 K + 64) eps is more than twice their total.  The bfloat16 candidate pass has
     // three times the accumulation steps and leaves out 4 * 2^-16 of the norms (see there).
     bool proven = true;
-    if (others != ~0ull) {   // there are train rows outside the re-scored set
+    if (others != 0xFFFFFFFFu) {   // there are train rows outside the re-scored set
         if (k1 == ~0ull) {
             proven = false;
         } else {
-            const unsigned ord = (unsigned)(others >> 32);
+            const unsigned ord = others;
             const unsigned u = ord ^ ((ord >> 31) ? 0x80000000u : 0xFFFFFFFFu);
             const double T = (double)__uint_as_float(u);
             const double qn = (double)a.q_norms[(size_t)qf * a.rows_cap + q];
@@ -780,17 +912,6 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
         a.knn_dist[o] = k0 == ~0ull ? FLT_MAX : __uint_as_float((unsigned)(k0 >> 32));
         a.knn_dist[o + 1] = k1 == ~0ull ? FLT_MAX : __uint_as_float((unsigned)(k1 >> 32));
     }
-}
-
-// Largest ||t||^2 of the packed rows (non-negative floats order like their bit patterns).
-__global__ void l2_norm_max_kernel(const float* __restrict__ norms, size_t n, float* __restrict__ out) {
-    float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float v = norms[i];
-        m = v > m ? v : m;   // a NaN norm is skipped; its row never ranks anyway
-    }
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
 }
 
 // The listed queries against every train row: one workgroup per entry (grid-stride), one train
@@ -917,24 +1038,13 @@ bool l2_use_bf16() {
     return !(e && e[0] == 'f');
 }
 
-// Split copies of packed rows (n_values floats) for the bfloat16 candidate pass.
-int l2_split(sfm_ctx* ctx, const float* packed, size_t n_values, int K, float* split) {
-    if (n_values == 0) return SFM_OK;
-    KernelTimer timer(ctx, KID_L2_PACK);
-    const unsigned blocks = (unsigned)std::min<size_t>((n_values + 255) / 256, 8192);
-    hipLaunchKernelGGL(l2_split_kernel, dim3(blocks), dim3(256), 0, ctx->stream, packed, n_values, K,
-                       reinterpret_cast<__bf16*>(split));
-    SFM_HIP_CHECK(ctx, hipGetLastError());
-    return SFM_OK;
-}
-
 // Scratch of one candidate / re-score / exhaustive sequence.
 struct L2Scratch {
     int32_t* cand;       // [problems][splits][rows_cap][4]
     float* cand_key;     // same layout
     float* cand_third;   // [problems][splits][rows_cap][2]
     float* norm_max;     // one float
-    int32_t* todo_count; // one int
+    int32_t* todo_count; // one int, right behind norm_max
     int32_t* todo;       // [problems][rows_cap][2]
     int32_t* knn_idx;    // [problems][rows_cap][2]
     float* knn_dist;
@@ -943,8 +1053,8 @@ void l2_scratch_carve(Carver& c, const L2Plan& plan, int rows_cap, size_t n_prob
     s->cand = c.take<int32_t>(n_problems * plan.splits * rows_cap * 4);
     s->cand_key = c.take<float>(n_problems * plan.splits * rows_cap * 4);
     s->cand_third = c.take<float>(n_problems * plan.splits * rows_cap * 2);
-    s->norm_max = c.take<float>(1);
-    s->todo_count = c.take<int32_t>(1);
+    s->norm_max = c.take<float>(2);   // the count follows the maximum: one memset clears both
+    s->todo_count = reinterpret_cast<int32_t*>(s->norm_max + 1);
     s->todo = c.take<int32_t>(n_problems * rows_cap * 2);
     s->knn_idx = c.take<int32_t>(n_problems * rows_cap * 2);
     s->knn_dist = c.take<float>(n_problems * rows_cap * 2);
@@ -957,12 +1067,14 @@ bool l2_force_exhaustive() {
 }
 
 // Candidate, re-score and exhaustive passes over packed data; writes s.knn_idx / s.knn_dist
-// [problem][rows_cap][2].  norms: ||row||^2 of every packed row (n_norms of them, rows_cap per
-// frame), used for the queries' norms and, through its maximum, for the error bound.
+// [problem][rows_cap][2].  q_norms / t_norms: ||row||^2 of every packed row, rows_cap per frame;
+// s.norm_max holds the largest of the train rows' (l2_pack), for the error bound; s.todo_count
+// is cleared here unless the caller has done so.
 int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const float* q_base,
-                  const float* t_base, const float* q_split, const float* t_split, const float* q_norms, const float* t_norms, size_t n_t_norms,
-                  size_t frame_floats, int rows_cap, const int32_t* d_counts, int nq_uniform, int nt_uniform,
-                  const int32_t* d_pairs, int n_problems, const L2Scratch& s) {
+                  const float* t_base, const float* q_split, const float* t_split, const float* q_norms,
+                  const float* t_norms, size_t frame_floats, int rows_cap, const int32_t* d_counts,
+                  int nq_uniform, int nt_uniform, const int32_t* d_pairs, int n_problems, const L2Scratch& s,
+                  bool clear_todo) {
     L2Args a{};
     a.q_base = q_base;
     a.t_base = t_base;
@@ -983,14 +1095,7 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     const long grid = (long)a.n_groups * a.blocks_per_group;
     if (grid <= 0) return SFM_OK;
     if (grid > 0x7fffffffL) return set_error(ctx, SFM_E_INVALID, "knn launch too large");
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(s.norm_max, 0, sizeof(float), ctx->stream));
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(s.todo_count, 0, sizeof(int32_t), ctx->stream));
-    if (n_t_norms > 0) {
-        const int blocks = (int)std::min<size_t>((n_t_norms + 255) / 256, 1024);
-        hipLaunchKernelGGL(l2_norm_max_kernel, dim3(blocks), dim3(256), 0, ctx->stream, t_norms, n_t_norms,
-                           s.norm_max);
-        SFM_HIP_CHECK(ctx, hipGetLastError());
-    }
+    if (clear_todo) SFM_HIP_CHECK(ctx, hipMemsetAsync(s.todo_count, 0, sizeof(int32_t), ctx->stream));
     // q_split / t_split: the rows split into bfloat16 halves (same row pitch), or null
     const bool bf16 = q_split && t_split;
     if (bf16) {
@@ -1025,8 +1130,10 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     // bfloat16 pass: three times the accumulation steps, 4 * 2^-16 of the norms left out by the
     // split, and the position tag in a key's five low bits (below 2^-18 of a key that is at
     // most twice the norms: 2^-17, counted as 2^-16)
-    r.key_error = bf16 ? (12.0 * plan.K + 64.0) * (double)FLT_EPSILON + 5.0 / 65536.0
-                       : (4.0 * plan.K + 64.0) * (double)FLT_EPSILON;
+    // either pass: the lane number in the six low bits of a key when the re-score pass ranks
+    // the candidates (below 2^-17 of the key, 2^-16 of the norms)
+    r.key_error = (bf16 ? (12.0 * plan.K + 64.0) * (double)FLT_EPSILON + 5.0 / 65536.0
+                        : (4.0 * plan.K + 64.0) * (double)FLT_EPSILON) + 1.0 / 65536.0;
     r.force_exhaustive = l2_force_exhaustive() ? 1 : 0;
     r.knn_idx = s.knn_idx;
     r.knn_dist = s.knn_dist;
@@ -1037,7 +1144,12 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     const dim3 rgrid((nq_max + kBlock / 64 - 1) / (kBlock / 64), n_problems);
     {
         KernelTimer timer(ctx, KID_L2_RESCORE);
-        hipLaunchKernelGGL(l2_rescore_kernel, rgrid, dim3(kBlock), 0, ctx->stream, r);
+        if (plan.K == 64)
+            hipLaunchKernelGGL(l2_rescore_kernel<1>, rgrid, dim3(kBlock), 0, ctx->stream, r);
+        else if (plan.K == 128)
+            hipLaunchKernelGGL(l2_rescore_kernel<2>, rgrid, dim3(kBlock), 0, ctx->stream, r);
+        else
+            hipLaunchKernelGGL(l2_rescore_kernel<4>, rgrid, dim3(kBlock), 0, ctx->stream, r);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
     // the listed queries (normally none: the workgroups read a zero count and leave)
@@ -1047,12 +1159,19 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     return SFM_OK;
 }
 
-int l2_pack(sfm_ctx* ctx, const void* src, int n, size_t stride_bytes, int dim, float* dst, int K,
-            float* norms) {
-    if (n <= 0) return SFM_OK;
+// One launch for up to two sets of rows (a set of zero rows is skipped).
+int l2_pack(sfm_ctx* ctx, const PackSet& s0, const PackSet& s1, int dim, int K) {
+    const int rows_per_block = (kBlock / 64) * kPackRowsPerWave;
+    PackArgs a;
+    a.set[0] = s0;
+    a.set[1] = s1;
+    a.blocks0 = (s0.rows + rows_per_block - 1) / rows_per_block;
+    a.dim = dim;
+    a.K = K;
+    const int blocks = a.blocks0 + (s1.rows + rows_per_block - 1) / rows_per_block;
+    if (blocks <= 0) return SFM_OK;
     KernelTimer timer(ctx, KID_L2_PACK);
-    hipLaunchKernelGGL(l2_pack_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream,
-                       static_cast<const uint8_t*>(src), n, stride_bytes, dim, dst, K, norms);
+    hipLaunchKernelGGL(l2_pack_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, a);
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
 }
@@ -1090,20 +1209,20 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
     float* qs = c.take<float>((size_t)nq * K);
     float* ts = c.take<float>((size_t)(nt > 0 ? nt : 1) * K);
     l2_scratch_carve(c, plan, rows_cap, 1, &sc);
+    // results go straight to the caller's arrays: one problem, so [q][2] is their layout
+    sc.knn_idx = d_idx;
+    sc.knn_dist = d_dist;
+    static_assert(sizeof(float) == sizeof(int32_t), "norm_max and todo_count are cleared together");
     SFM_HIP_CHECK(ctx, hipMemsetAsync(ctx->stats, 0, sizeof(int32_t), ctx->stream));
-    SFM_RETURN_IF(l2_pack(ctx, d_q, nq, q_stride, dim, qp, K, qn));
-    SFM_RETURN_IF(l2_pack(ctx, d_t, nt, t_stride, dim, tp, K, tn));
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(sc.norm_max, 0, 2 * sizeof(float), ctx->stream));
     const bool bf16 = l2_use_bf16();
-    if (bf16) {
-        SFM_RETURN_IF(l2_split(ctx, qp, (size_t)nq * K, K, qs));
-        SFM_RETURN_IF(l2_split(ctx, tp, (size_t)nt * K, K, ts));
-    }
+    const PackSet qset{reinterpret_cast<const uint8_t*>(d_q), nq, nq > 0 ? nq : 1, 0, q_stride, qp,
+                       bf16 ? reinterpret_cast<__bf16*>(qs) : nullptr, qn, nullptr};
+    const PackSet tset{reinterpret_cast<const uint8_t*>(d_t), nt, nt > 0 ? nt : 1, 0, t_stride, tp,
+                       bf16 ? reinterpret_cast<__bf16*>(ts) : nullptr, tn, sc.norm_max};
+    SFM_RETURN_IF(l2_pack(ctx, qset, tset, dim, K));
     SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, qp, tp, bf16 ? qs : nullptr, bf16 ? ts : nullptr, qn, tn,
-                                (size_t)nt, 0, rows_cap, nullptr, nq, nt, nullptr, 1, sc));
-    SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, sc.knn_idx, sizeof(int32_t) * 2 * nq, hipMemcpyDeviceToDevice,
-                                      ctx->stream));
-    SFM_HIP_CHECK(ctx, hipMemcpyAsync(d_dist, sc.knn_dist, sizeof(float) * 2 * nq, hipMemcpyDeviceToDevice,
-                                      ctx->stream));
+                                0, rows_cap, nullptr, nq, nt, nullptr, 1, sc, false));
     return SFM_OK;
 }
 
@@ -1139,7 +1258,7 @@ size_t l2_match_pairs_workspace(int n_frames, int rows_per_frame, int dim, int n
     return c.total();
 }
 
-// Every frame is repacked (zero-padded to K floats, norms computed) on each call.
+// Every frame is repacked (zero-padded to K floats, norms computed, split) on each call.
 int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_frames,
                         size_t frame_stride, int rows_per_frame, const int32_t* d_counts, int dim,
                         const int32_t* d_pairs, int n_pairs, float ratio, sfm_dmatch* d_matches,
@@ -1160,21 +1279,20 @@ int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_fr
     Carver c(ws);
     l2_pairs_carve(c, plan, n_frames, rows_per_frame, chunk, &b);
     SFM_HIP_CHECK(ctx, hipMemsetAsync(ctx->stats, 0, sizeof(int32_t), ctx->stream));
-    for (int f = 0; f < n_frames; ++f)
-        SFM_RETURN_IF(l2_pack(ctx, reinterpret_cast<const uint8_t*>(d_desc) + f * frame_stride,
-                              rows_per_frame, (size_t)dim * 4, dim,
-                              b.packed + (size_t)f * rows_per_frame * plan.K, plan.K,
-                              b.norms + (size_t)f * rows_per_frame));
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.sc.norm_max, 0, sizeof(float), ctx->stream));
     const bool bf16 = l2_use_bf16();
-    if (bf16) SFM_RETURN_IF(l2_split(ctx, b.packed, (size_t)n_frames * rows_per_frame * plan.K, plan.K, b.split));
+    // every frame in one launch; rows beyond a frame's count are packed too (they are never read)
+    const PackSet frames{reinterpret_cast<const uint8_t*>(d_desc), n_frames * rows_per_frame, rows_per_frame,
+                         frame_stride, (size_t)dim * 4, b.packed,
+                         bf16 ? reinterpret_cast<__bf16*>(b.split) : nullptr, b.norms, b.sc.norm_max};
+    SFM_RETURN_IF(l2_pack(ctx, frames, PackSet{}, dim, plan.K));
     const float* split = bf16 ? b.split : nullptr;
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
         const int np = chunk < n_pairs - p0 ? chunk : n_pairs - p0;
         const int32_t* pairs = d_pairs + 2 * (size_t)p0;
         SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, b.packed, b.packed, split, split, b.norms, b.norms,
-                                    (size_t)n_frames * rows_per_frame, (size_t)rows_per_frame * plan.K,
-                                    rows_per_frame, d_counts, rows_per_frame, rows_per_frame, pairs, 2 * np,
-                                    b.sc));
+                                    (size_t)rows_per_frame * plan.K, rows_per_frame, d_counts,
+                                    rows_per_frame, rows_per_frame, pairs, 2 * np, b.sc, true));
         SFM_RETURN_IF(launch_ratio_cross_knn(ctx, b.sc.knn_idx, b.sc.knn_dist, rows_per_frame, d_counts,
                                              rows_per_frame, pairs, np, ratio, b.best, b.best_dist,
                                              d_matches + (size_t)p0 * cap, cap,
