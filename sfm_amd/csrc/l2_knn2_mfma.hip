@@ -1,23 +1,25 @@
-// Brute-force L2 2-nearest-neighbour search for float descriptors on the fp32
-// matrix cores of gfx950.
+// Brute-force L2 2-nearest-neighbour search for float descriptors on the matrix cores of gfx950.
 //
 // Replaces cv::BFMatcher(NORM_L2 / NORM_L2SQR)::knnMatch(q, t, out, 2) as called
 // from DescriptorMatcher::ratioMaches (Source Files/feature_processing.cpp:121)
 // for the "BRUTEFORCE" and "BRUTEFORCE_SL2" matcher types (:111, :115).
 //
-// Two passes.
-//   1. Candidate pass (MFMA).  ||q - t||^2 - ||q||^2 = ||t||^2 - 2 q.t is formed as a
-//      dense contraction on v_mfma_f32_32x32x2_f32: the train tile is the A
-//      operand (rows = train), the query tile the B operand (columns = queries),
-//      so each lane's accumulator registers hold 16 train candidates of ONE query
-//      and the running best-two list of that query lives in the lane's registers
-//      with no cross-lane traffic.  The queries of a wave (pre-scaled by -2, an
-//      exact scaling) stay in VGPRs for the whole kernel; train tiles are copied
-//      global -> LDS by global_load_lds (XOR-swizzled through the source
-//      address so that the ds_read_b128 fragment reads are conflict-free); the
-//      accumulators are initialised with ||t||^2 straight from LDS, so the
-//      accumulator is the ranking key when the k-loop ends.  Every (lane half,
-//      train split) keeps its own best two, which are written out as candidates.
+// Passes.
+//   0. Packing (l2_pack_kernel): rows zero-padded to K floats, ||row||^2, and the rows split into
+//      bfloat16 halves for pass 1.
+//   1. Candidate pass (MFMA).  The ranking key ||q - t||^2 - ||q||^2 = ||t||^2 - 2 q.t is formed as
+//      a dense contraction: the train tile is the A operand (rows = train), the query tile the
+//      B operand (columns = queries), so each lane's accumulator registers hold 16 train
+//      candidates of ONE query and the running best-two list of that query lives in the lane's
+//      registers with no cross-lane traffic.  The queries of a wave stay in VGPRs for the whole
+//      kernel; train tiles are copied global -> LDS by global_load_lds (XOR-swizzled through the
+//      source address so that the ds_read_b128 fragment reads are conflict-free); the
+//      accumulators start at the norm term, so the accumulator is the ranking key when the
+//      k-loop ends.  Every (lane half, train split) keeps its own best two, which are written
+//      out as candidates.  By default the contraction runs on the bfloat16 matrix cores, every
+//      float split into two bfloat16 halves (l2_candidates_bf16_kernel, sixteen times the rate);
+//      SFM_L2_MFMA=f32 selects v_mfma_f32_32x32x2_f32 on unsplit rows (l2_candidates_kernel).
+//      The key only ranks: its rounding is covered by the proof of pass 2.
 //   2. Re-score pass.  For the eight candidates of a query with the smallest ranking
 //      keys the squared distance is recomputed as the sequential float sum
 //      d += (a-b)*(a-b)  (the scalar order of OpenCV's normL2Sqr), the square root
