@@ -205,6 +205,27 @@ def test_l2_exhaustive_pass_alone(ctx, oracle, monkeypatch):
     assert _tuples(got) == _tuples(want)
 
 
+@pytest.mark.parametrize("scale", [1.0, 1e-20, 1e18])
+def test_l2_zero_rows_and_extreme_magnitudes(ctx, oracle, scale):
+    """All-zero train rows and an all-zero query give ranking keys of exactly zero, tiny data
+    gives keys in the denormal range, huge data keys near the top of the float range: the
+    candidate pass must keep telling rows apart (its keys carry a position tag in their low
+    bits) and the result stays the oracle's, ties in index order."""
+    from sfm_amd import capi, synth
+
+    q, t = synth.float_descriptors(300, 2500, dim=128, seed=31, integer=False)
+    q = (q * np.float32(scale)).astype(np.float32)
+    t = (t * np.float32(scale)).astype(np.float32)
+    t[[5, 64, 65, 700, 1999, 2400]] = 0.0
+    q[[0, 17]] = 0.0
+    q[40] = t[123]
+    oidx, odist = oracle.knn2_l2(q, t, squared=True)
+    idx, dist = ctx.knn2(capi.NORM_L2SQR, q, t)
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_array_equal(dist, odist)
+    assert list(idx[0]) == [5, 64]            # the zero query: the first two zero rows
+
+
 @pytest.mark.parametrize("dim", [32, 64, 128, 100])
 @pytest.mark.parametrize("integer", [True, False])
 def test_l2_both_matrix_core_passes(ctx, oracle, monkeypatch, dim, integer):
