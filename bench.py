@@ -71,7 +71,7 @@ def hamming_roofline(prof, n_directions, rows, desc_bytes, launches_note):
             "traffic": None}
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, no sparsity
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # bf16 and fp16, dense, no sparsity
 
 KPS = 8192
 DESC_BYTES = 32
@@ -540,18 +540,20 @@ def run_c4(args, rank, world, local):
         avg_s = ms / cnt * 1e-3
         flop = 2.0 * nq * nt * dim
         tf = flop / avg_s / 1e12
-        # The candidate pass runs on the bfloat16 matrix cores (every float split in two bf16
-        # halves, three products per term) unless SFM_L2_MFMA=f32 keeps it on the fp32 ones.
-        bf16 = not os.environ.get("SFM_L2_MFMA", "").startswith("f")
-        peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
-        roof = {"kernel": "l2_candidates_bf16_kernel" if bf16 else "l2_candidates_kernel",
-                "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+        # The candidate pass runs on the fp16 matrix cores (one product per term on fp16 copies of
+        # the rows) unless SFM_L2_MFMA selects the bfloat16 split (three products) or the fp32 ones.
+        env = os.environ.get("SFM_L2_MFMA", "")
+        mode = "f32" if env.startswith("f3") else "bf16" if env.startswith("b") else "f16"
+        peak = MFMA_F32_PEAK_TFLOPS if mode == "f32" else MFMA_BF16_PEAK_TFLOPS
+        roof = {"kernel": "l2_candidates_kernel" if mode == "f32" else "l2_candidates_narrow_kernel",
+                "operands": mode, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(tf / peak, 4), "avg_launch_us": round(avg_s * 1e6, 2), "traffic": None,
                 "algorithmic_per_launch": f"2 x {nq} x {nt} x {dim} = {flop:.4g} FLOP"}
-        if bf16:
+        if mode == "bf16":
             roof["issued"] = {"achieved": round(3 * tf, 2), "frac": round(3 * tf / peak, 4),
                               "note": "three bf16 products per term of the dot product "
                                       "(high*high, high*low, low*high)"}
+        if mode != "f32":
             roof["vs_fp32_matrix_peak"] = round(tf / MFMA_F32_PEAK_TFLOPS, 4)
         res[name] = {"ms_per_step": round(1e3 * dt / args.steps, 4),
                      "kernels": {k: kernel_line(prof, k) for k in sorted(prof)},

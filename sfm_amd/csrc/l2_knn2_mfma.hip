@@ -61,6 +61,8 @@ struct L2Args {
     const float* q_base;  // packed rows of K floats
     const float* t_base;
     const float* t_norms;  // ||t||^2 per packed train row, same frame layout (rows_cap per frame)
+    const float* t_acc0;   // start values of the narrow passes: -||t||^2 / 2 (fp16: times s^2)
+    const float* narrow_scale;  // fp16 pass: s^2, 1 / s^2
     size_t frame_floats;   // floats per frame in q_base / t_base
     int rows_cap;          // rows per frame in the norm array and the candidate array
     const int32_t* counts;
@@ -320,6 +322,16 @@ __global__ __launch_bounds__(kBlock) void l2_candidates_kernel(L2Args a) {
 }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+template <bool F16> struct NarrowFragment { typedef bf16x8 type; };
+template <> struct NarrowFragment<true> { typedef halfx8 type; };
+
+__device__ __forceinline__ floatx16 narrow_mfma(bf16x8 a, bf16x8 b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ floatx16 narrow_mfma(halfx8 a, halfx8 b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 // The candidate pass on the bfloat16 matrix cores (sixteen times the rate of the fp32 ones).
 // Every float x of the packed rows is split into xh + xl, two bfloat16 values that carry its
@@ -333,10 +345,23 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // interleave, and the fold -- four instructions per key -- runs underneath the matrix
 // instructions of the next tile.  (With 64 queries per wave and one wave per SIMD the same fold
 // left the matrix pipe idle half of the time.)
-template <int K, int NT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void l2_candidates_bf16_kernel(L2Args a) {
-    constexpr int kChunksPerRow = K / 4;             // 16-byte chunks of a split row
-    constexpr int kTileFloats = kTileRows * K;
+//
+// F16: the narrow rows are single fp16 copies x * s of the floats, s a power of two common to
+// all rows that brings the largest below 2^15 (l2_narrow_kernel), and q.t is one
+// v_mfma_f32_32x32x16_f16 contraction -- a third of the matrix work on rows half as wide.  What
+// the rounding to eleven bits leaves out is bounded per query by the norms of the rows'
+// residuals x - fp16(x s) / s, which l2_narrow_kernel measures (Cauchy-Schwarz; zero for
+// integer-valued descriptors up to 2048), and the re-score pass adds that bound to E.  The
+// accumulators and the running lists then hold keys times s^2; the lists are scaled back when
+// they are written out.
+template <int K, int NT, int WAVES, bool F16>
+__global__ __launch_bounds__(64 * WAVES) void l2_candidates_narrow_kernel(L2Args a) {
+    typedef typename NarrowFragment<F16>::type frag;
+    constexpr int kRowFloats = F16 ? K / 2 : K;      // a narrow row in floats
+    constexpr int kChunksPerRow = kRowFloats / 4;    // 16-byte chunks of a narrow row
+    constexpr int kSwizzle = kChunksPerRow >= 16 ? 15 : kChunksPerRow - 1;
+    constexpr int kTerms = F16 ? 1 : 3;              // contractions per step
+    constexpr int kTileFloats = kTileRows * kRowFloats;
     constexpr int kQPerWave = 32 * NT;
     constexpr int kQPerBlock = WAVES * kQPerWave;
     static_assert(kChunksPerRow % WAVES == 0, "the waves share the staging of a tile evenly");
@@ -365,22 +390,22 @@ __global__ __launch_bounds__(64 * WAVES) void l2_candidates_bf16_kernel(L2Args a
     if (q0 >= nq) return;
     const float* qrows = a.q_base + (size_t)qf * a.frame_floats;
     const float* trows = a.t_base + (size_t)tf * a.frame_floats;
-    const float* tnorm = a.t_norms + (size_t)tf * a.rows_cap;
+    const float* tacc0 = a.t_acc0 + (size_t)tf * a.rows_cap;   // -||t||^2 / 2 (times s^2)
 
     // B operand: this lane's query columns, upper and lower halves, resident for the whole
     // kernel.  Element [n][s] holds dimensions 16 s + 8 lh .. + 7 of query
     // q0 + wave * kQPerWave + 32 n + li.
-    bf16x8 qh[NT][kSteps], ql[NT][kSteps];
+    frag qh[NT][kSteps], ql[NT][kSteps];   // (ql: bfloat16 split only)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int qi = q0 + wave * kQPerWave + 32 * n + li;
-        const bf16x8* src = reinterpret_cast<const bf16x8*>(qrows + (size_t)(qi < nq ? qi : 0) * K);
+        const frag* src = reinterpret_cast<const frag*>(qrows + (size_t)(qi < nq ? qi : 0) * kRowFloats);
 #pragma unroll
         for (int s = 0; s < kSteps; ++s) {
-            bf16x8 h = src[2 * s + lh], l = src[K / 8 + 2 * s + lh];
+            frag h = src[2 * s + lh], l = F16 ? h : src[K / 8 + 2 * s + lh];
             if (qi >= nq) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) h[e] = l[e] = (__bf16)0.f;
+                for (int e = 0; e < 8; ++e) h[e] = l[e] = 0;
             }
             qh[n][s] = h;
             ql[n][s] = l;
@@ -416,16 +441,16 @@ __global__ __launch_bounds__(64 * WAVES) void l2_candidates_bf16_kernel(L2Args a
             const int instr = wave * (kChunksPerRow / WAVES) + it;
             const int p = instr * 64 + lane;
             const int row = p / kChunksPerRow, cpos = p % kChunksPerRow;
-            const int c = cpos ^ (row & 15);
+            const int c = cpos ^ (row & kSwizzle);
             int trow = tbase + row;
             trow = trow < nt ? trow : nt - 1;  // clamped rows are masked by a norm of kNoRow
-            glds16(trows + (size_t)trow * K + c * 4, dst + instr * 256);
+            glds16(trows + (size_t)trow * kRowFloats + c * 4, dst + instr * 256);
         }
         if (tid < kTileRows) {
             const int trow = tbase + tid;
             // q.t changes nothing in kNoRowAcc (its ulp is 2^103): a masked row's key is never
             // below a best
-            norm_lds[buf * kTileRows + tid] = trow < t_end ? -0.5f * tnorm[trow] : kNoRowAcc;
+            norm_lds[buf * kTileRows + tid] = trow < t_end ? tacc0[trow] : kNoRowAcc;
         }
     };
 
@@ -482,7 +507,7 @@ __global__ __launch_bounds__(64 * WAVES) void l2_candidates_bf16_kernel(L2Args a
     };
 
     constexpr int kKeys = 2 * NT * 16;             // keys of a finished tile per lane
-    constexpr int kMfmas = kSteps * 2 * NT * 3;    // MFMAs of a tile per wave
+    constexpr int kMfmas = kSteps * 2 * NT * kTerms;   // MFMAs of a tile per wave
     constexpr int kFoldUnits = kMfmas - 3 * NT;    // the last 3 NT carry the merges
     static_assert(kFoldUnits > 0, "the fold needs room beside the merges");
     auto tile_step = [&](floatx16 (&accC)[2][NT], const floatx16 (&accF)[2][NT], int k) {
@@ -507,16 +532,19 @@ __global__ __launch_bounds__(64 * WAVES) void l2_candidates_bf16_kernel(L2Args a
         }
         // fragments of step s: chunk 2 s + lh of the upper halves, the same chunk of the lower
         // halves K / 8 chunks further on
-        auto load_a = [&](int s, bf16x8 (&ah)[2], bf16x8 (&al)[2]) {
+        auto load_a = [&](int s, frag (&ah)[2], frag (&al)[2]) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int row = 32 * mt + li;
-                const int ch = (2 * s + lh) ^ (row & 15), cl = (K / 8 + 2 * s + lh) ^ (row & 15);
-                ah[mt] = *reinterpret_cast<const bf16x8*>(tile + row * K + ch * 4);
-                al[mt] = *reinterpret_cast<const bf16x8*>(tile + row * K + cl * 4);
+                const int ch = (2 * s + lh) ^ (row & kSwizzle);
+                ah[mt] = *reinterpret_cast<const frag*>(tile + row * kRowFloats + ch * 4);
+                if (!F16) {
+                    const int cl = (K / 8 + 2 * s + lh) ^ (row & kSwizzle);
+                    al[mt] = *reinterpret_cast<const frag*>(tile + row * kRowFloats + cl * 4);
+                }
             }
         };
-        bf16x8 ah[2], al[2], ah_next[2], al_next[2];
+        frag ah[2], al[2], ah_next[2], al_next[2];
         load_a(0, ah, al);
         // the fold of the finished tile is dealt over the MFMAs of this one, in a pinned order
         // (see the fp32 kernel)
@@ -528,14 +556,14 @@ __global__ __launch_bounds__(64 * WAVES) void l2_candidates_bf16_kernel(L2Args a
             // the three products of one accumulator are 2 NT MFMAs apart: none waits for the
             // one before it, and the fold issues underneath them
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int term = 0; term < kTerms; ++term)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        const bf16x8 av = term == 2 ? al[mt] : ah[mt];
-                        const bf16x8 bv = term == 1 ? ql[n][s] : qh[n][s];
-                        accC[mt][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, accC[mt][n], 0, 0, 0);
+                        const frag av = term == 2 ? al[mt] : ah[mt];
+                        const frag bv = term == 1 ? ql[n][s] : qh[n][s];
+                        accC[mt][n] = narrow_mfma(av, bv, accC[mt][n]);
                         if (unit < kFoldUnits) {
 #pragma unroll
                             for (int kq = (unit * kKeys) / kFoldUnits; kq < ((unit + 1) * kKeys) / kFoldUnits; ++kq)
@@ -573,6 +601,7 @@ __global__ __launch_bounds__(64 * WAVES) void l2_candidates_bf16_kernel(L2Args a
         for (int u = 0; u < 3 * NT; ++u) merge(u / 3, u % 3, tbase_last);
     }
 
+    const float unscale = F16 ? a.narrow_scale[1] : 1.f;   // 1 / s^2
     const size_t cbase = (((size_t)problem * a.splits + split) * a.rows_cap) * 4;
     int32_t* cand = a.cand + cbase;
     float* ckey = a.cand_key + cbase;
@@ -582,9 +611,10 @@ __global__ __launch_bounds__(64 * WAVES) void l2_candidates_bf16_kernel(L2Args a
         if (qi < nq) {
             cand[(size_t)qi * 4 + 2 * lh] = bidx0[n];
             cand[(size_t)qi * 4 + 2 * lh + 1] = bidx1[n];
-            ckey[(size_t)qi * 4 + 2 * lh] = best0[n];
-            ckey[(size_t)qi * 4 + 2 * lh + 1] = best1[n];
-            a.cand_third[cbase / 2 + (size_t)qi * 2 + lh] = third[n];
+            // (a power of two; an entry without a row may leave the float range: it is not read)
+            ckey[(size_t)qi * 4 + 2 * lh] = best0[n] * unscale;
+            ckey[(size_t)qi * 4 + 2 * lh + 1] = best1[n] * unscale;
+            a.cand_third[cbase / 2 + (size_t)qi * 2 + lh] = third[n] * unscale;
         }
     }
 }
@@ -602,7 +632,9 @@ struct PackSet {
     float* dst;                        // [rows][K]
     __bf16* split;                     // [rows][2 K], or null
     float* norms;                      // [rows]
+    float* acc0;                       // [rows]: -||row||^2 / 2, or null
     float* norm_max;                   // one float, or null
+    float* all_max;                    // one float shared by both sets, or null
 };
 struct PackArgs {
     PackSet set[2];
@@ -662,13 +694,108 @@ __global__ __launch_bounds__(kBlock) void l2_pack_kernel(PackArgs a) {
             }
         }
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) p.norms[row] = acc;
+        if (lane == 0) {
+            p.norms[row] = acc;
+            if (p.acc0) p.acc0[row] = -0.5f * acc;
+        }
         largest = acc > largest ? acc : largest;
     }
     // the maximum only grows: a wave whose rows do not exceed what is there leaves it alone
     // (thousands of atomics on one address would take longer than the packing)
     if (p.norm_max && lane == 0 && largest > *reinterpret_cast<volatile float*>(p.norm_max))
         atomicMax(reinterpret_cast<unsigned*>(p.norm_max), __float_as_uint(largest));
+    if (p.all_max && lane == 0 && largest > *reinterpret_cast<volatile float*>(p.all_max))
+        atomicMax(reinterpret_cast<unsigned*>(p.all_max), __float_as_uint(largest));
+}
+
+// Packed rows -> single fp16 copies for the fp16 candidate pass, in one launch for up to two
+// sets.  s = 2^shift is common to all rows: the largest norm times s stays below 2^15, so no
+// element leaves the fp16 range, and products of scaled elements are exact in the matrix
+// pipe's fp32.  Per row: the fp16 row fp16(x s) (round to nearest even), the norm of what the
+// rounding left out, ||x - fp16(x s) / s|| (the differences are exact in fp32; the sum is
+// rounded up by a part in a thousand), the accumulator start value -||x||^2 s^2 / 2; per set the
+// largest residual norm (res_max zero before the launch).  scale_out: s^2 and 1 / s^2.
+struct NarrowSet {
+    const float* packed;   // [rows][K]
+    const float* norms;    // [rows]
+    int rows;
+    _Float16* half;        // [rows][K]
+    float* res;            // [rows]
+    float* acc0;           // [rows], or null
+    float* res_max;        // one float, or null
+};
+struct NarrowArgs {
+    NarrowSet set[2];
+    int blocks0;
+    int K;
+    const float* all_max;  // largest ||row||^2 of both sets
+    float* scale_out;
+};
+
+__global__ __launch_bounds__(kBlock) void l2_narrow_kernel(NarrowArgs a) {
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+    const bool second = (int)blockIdx.x >= a.blocks0;
+    const NarrowSet& p = a.set[second ? 1 : 0];
+    const int block = second ? blockIdx.x - a.blocks0 : blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int row0 = (block * (kBlock / 64) + (threadIdx.x >> 6)) * kPackRowsPerWave;
+    const int K = a.K;
+    // sqrt(m) < 2^e, so |x| s < 2^15 for every element x of every row
+    const float m = *a.all_max;
+    int shift = 0;
+    if (m > 0.f && m < INFINITY) {
+        int ex;
+        (void)frexpf(m, &ex);
+        shift = 15 - ((ex + 1) >> 1);
+        shift = shift > 60 ? 60 : shift;   // s^2 stays a float; tiny rows are scaled less
+    }
+    const float s = ldexpf(1.f, shift), inv_s = ldexpf(1.f, -shift);
+    const float s2 = ldexpf(1.f, 2 * shift);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.scale_out[0] = s2;
+        a.scale_out[1] = ldexpf(1.f, -2 * shift);
+    }
+    floatx2 v[kPackRowsPerWave][2];
+#pragma unroll
+    for (int r = 0; r < kPackRowsPerWave; ++r) {
+        const int row = min(row0 + r, p.rows - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = 2 * (lane + 64 * i);
+            v[r][i] = j < K ? *reinterpret_cast<const floatx2*>(p.packed + (size_t)row * K + j) : floatx2{0.f, 0.f};
+        }
+    }
+    float largest = 0.f;
+#pragma unroll
+    for (int r = 0; r < kPackRowsPerWave; ++r) {
+        const int row = row0 + r;
+        if (row >= p.rows) break;   // wave-uniform
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = 2 * (lane + 64 * i);
+            if (j < K) {
+                const floatx2 x = v[r][i];
+                halfx2 h;
+                h.x = (_Float16)(x.x * s);
+                h.y = (_Float16)(x.y * s);
+                *reinterpret_cast<halfx2*>(p.half + (size_t)row * K + j) = h;
+                const float d0 = x.x - (float)h.x * inv_s, d1 = x.y - (float)h.y * inv_s;
+                acc += d0 * d0;
+                acc += d1 * d1;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        const float res = sqrtf(acc) * 1.001f;
+        if (lane == 0) {
+            p.res[row] = res;
+            if (p.acc0) p.acc0[row] = -0.5f * p.norms[row] * s2;
+        }
+        largest = res > largest ? res : largest;
+    }
+    if (p.res_max && lane == 0 && largest > *reinterpret_cast<volatile float*>(p.res_max))
+        atomicMax(reinterpret_cast<unsigned*>(p.res_max), __float_as_uint(largest));
 }
 
 // Squared distance as the sequential float sum d += (a-b)*(a-b), the scalar order of OpenCV's
@@ -706,6 +833,8 @@ struct RescoreArgs {
     const float* q_norms;  // ||q||^2 per packed row, rows_cap per frame
     const float* t_norm_max;  // largest ||t||^2 of any packed row (one float)
     double key_error;  // bound on |ranking key + ||q||^2 - sequential distance| / (||q||^2 + max ||t||^2)
+    const float* q_res;      // fp16 pass: residual norm of every query row (rows_cap per frame), or null
+    const float* t_res_max;  // fp16 pass: largest residual norm of a train row
     int force_exhaustive;
     int32_t* knn_idx;  // [problem][rows_cap][2]
     float* knn_dist;
@@ -892,7 +1021,14 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
             const unsigned u = ord ^ ((ord >> 31) ? 0x80000000u : 0xFFFFFFFFu);
             const double T = (double)__uint_as_float(u);
             const double qn = (double)a.q_norms[(size_t)qf * a.rows_cap + q];
-            const double E = a.key_error * (qn + (double)*a.t_norm_max);
+            const double tmax = (double)*a.t_norm_max;
+            double E = a.key_error * (qn + tmax);
+            if (a.q_res) {
+                // fp16 pass: |q.t - q'.t'| <= |q - q'| |t| + |q| |t - t'| + |q - q'| |t - t'| for
+                // the rounded rows q', t' (Cauchy-Schwarz), twice that in the key
+                const double rq = (double)a.q_res[(size_t)qf * a.rows_cap + q], rt = (double)*a.t_res_max;
+                E += 2.002 * (rq * sqrt(tmax) + sqrt(qn) * rt + rq * rt);
+            }
             // NORM_L2 ranks by the rounded square root, which maps neighbouring sums to one
             // value: a row ties or wins only if its sum is below the square of the next float
             const float d1 = __uint_as_float((unsigned)(k1 >> 32));
@@ -1020,11 +1156,26 @@ int make_l2_plan(const sfm_ctx* ctx, int dim, int nq_max, int nt_max, int n_prob
     return SFM_OK;
 }
 
+// Which matrix cores rank the candidates.  SFM_L2_MFMA=f32 / bf16 select the other passes (a
+// measuring and testing aid, read per call); the default is the fp16 pass.
+enum L2Mode { kL2F32, kL2Bf16, kL2F16 };
+L2Mode l2_mode() {
+    const char* e = getenv("SFM_L2_MFMA");
+    if (!e) return kL2F16;
+    if (e[0] == 'f' && e[1] == '3') return kL2F32;
+    if (e[0] == 'b') return kL2Bf16;
+    return kL2F16;
+}
+
 template <int K, int NT>
-int launch_candidates(sfm_ctx* ctx, const L2Args& a, long grid, bool bf16) {
+int launch_candidates(sfm_ctx* ctx, const L2Args& a, long grid, L2Mode mode) {
     KernelTimer timer(ctx, KID_L2_CANDIDATES);
-    if (bf16)   // the same queries per workgroup, one 32-query column block per wave
-        hipLaunchKernelGGL((l2_candidates_bf16_kernel<K, 1, 4 * NT>), dim3((unsigned)grid),
+    // narrow passes: the same queries per workgroup, one 32-query column block per wave
+    if (mode == kL2F16)
+        hipLaunchKernelGGL((l2_candidates_narrow_kernel<K, 1, 4 * NT, true>), dim3((unsigned)grid),
+                           dim3(64 * 4 * NT), 0, ctx->stream, a);
+    else if (mode == kL2Bf16)
+        hipLaunchKernelGGL((l2_candidates_narrow_kernel<K, 1, 4 * NT, false>), dim3((unsigned)grid),
                            dim3(64 * 4 * NT), 0, ctx->stream, a);
     else
         hipLaunchKernelGGL((l2_candidates_kernel<K, NT>), dim3((unsigned)grid), dim3(kBlock), 0,
@@ -1033,34 +1184,28 @@ int launch_candidates(sfm_ctx* ctx, const L2Args& a, long grid, bool bf16) {
     return SFM_OK;
 }
 
-// SFM_L2_MFMA=f32 keeps the candidate pass on the fp32 matrix cores (a measuring aid, read per
-// call); the default is the bfloat16 split.
-bool l2_use_bf16() {
-    const char* e = getenv("SFM_L2_MFMA");
-    return !(e && e[0] == 'f');
-}
-
 // Scratch of one candidate / re-score / exhaustive sequence.
 struct L2Scratch {
     int32_t* cand;       // [problems][splits][rows_cap][4]
     float* cand_key;     // same layout
     float* cand_third;   // [problems][splits][rows_cap][2]
-    float* norm_max;     // one float
-    int32_t* todo_count; // one int, right behind norm_max
+    float* scalars;      // kScalar* below
     int32_t* todo;       // [problems][rows_cap][2]
     int32_t* knn_idx;    // [problems][rows_cap][2]
     float* knn_dist;
 };
+// scalars: the first four are cleared before the rows are packed
+enum { kScalarNormMax = 0, kScalarTodoCount, kScalarAllMax, kScalarResMax, kScalarScale2, kScalarUnscale2, kScalars };
 void l2_scratch_carve(Carver& c, const L2Plan& plan, int rows_cap, size_t n_problems, L2Scratch* s) {
     s->cand = c.take<int32_t>(n_problems * plan.splits * rows_cap * 4);
     s->cand_key = c.take<float>(n_problems * plan.splits * rows_cap * 4);
     s->cand_third = c.take<float>(n_problems * plan.splits * rows_cap * 2);
-    s->norm_max = c.take<float>(2);   // the count follows the maximum: one memset clears both
-    s->todo_count = reinterpret_cast<int32_t*>(s->norm_max + 1);
+    s->scalars = c.take<float>(kScalars);
     s->todo = c.take<int32_t>(n_problems * rows_cap * 2);
     s->knn_idx = c.take<int32_t>(n_problems * rows_cap * 2);
     s->knn_dist = c.take<float>(n_problems * rows_cap * 2);
 }
+static_assert(sizeof(float) == sizeof(int32_t), "the query count lives among the float scalars");
 
 // SFM_L2_EXHAUSTIVE=1 sends every query through the exhaustive pass (a testing aid, read per call).
 bool l2_force_exhaustive() {
@@ -1068,20 +1213,84 @@ bool l2_force_exhaustive() {
     return e && e[0] == '1';
 }
 
-// Candidate, re-score and exhaustive passes over packed data; writes s.knn_idx / s.knn_dist
-// [problem][rows_cap][2].  q_norms / t_norms: ||row||^2 of every packed row, rows_cap per frame;
-// s.norm_max holds the largest of the train rows' (l2_pack), for the error bound; s.todo_count
-// is cleared here unless the caller has done so.
-int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const float* q_base,
-                  const float* t_base, const float* q_split, const float* t_split, const float* q_norms,
-                  const float* t_norms, size_t frame_floats, int rows_cap, const int32_t* d_counts,
-                  int nq_uniform, int nt_uniform, const int32_t* d_pairs, int n_problems, const L2Scratch& s,
+// The rows of one matching job in the layouts of the passes (rows_cap rows per frame).
+struct L2Rows {
+    float* packed;   // [rows][K] zero-padded floats
+    float* narrow;   // [rows][K] bfloat16 pairs (K floats) or [rows][K] fp16 (K / 2 floats)
+    float* norms;    // ||row||^2
+    float* acc0;     // start value of the narrow passes' accumulators
+    float* res;      // fp16 pass: residual norm
+};
+void l2_rows_carve(Carver& c, size_t rows, int K, L2Rows* r) {
+    r->packed = c.take<float>(rows * K);
+    r->narrow = c.take<float>(rows * K);
+    r->norms = c.take<float>(rows);
+    r->acc0 = c.take<float>(rows);
+    r->res = c.take<float>(rows);
+}
+
+// Packing of up to two sets of rows for `mode` (a set of zero rows is skipped): one launch, and
+// a second one for the fp16 rows, whose scale depends on the largest norm of all.  The train
+// rows are set 1: their largest norm and residual go to the scalars.  The first four scalars
+// must be zero.
+struct L2Source {
+    const void* src;
+    int rows, rows_per_group;
+    size_t group_stride, row_stride;
+};
+int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, const L2Rows& rows0, const L2Source& src1,
+            const L2Rows& rows1, bool set0_is_train, int dim, int K, float* scalars) {
+    const int rows_per_block = (kBlock / 64) * kPackRowsPerWave;
+    const L2Source* src[2] = {&src0, &src1};
+    const L2Rows* rows[2] = {&rows0, &rows1};
+    const int blocks0 = (src0.rows + rows_per_block - 1) / rows_per_block;
+    const int blocks = blocks0 + (src1.rows + rows_per_block - 1) / rows_per_block;
+    if (blocks <= 0) return SFM_OK;
+    KernelTimer timer(ctx, KID_L2_PACK);
+    PackArgs a{};
+    NarrowArgs n{};
+    for (int i = 0; i < 2; ++i) {
+        const bool train = i == 1 || set0_is_train;
+        a.set[i] = PackSet{static_cast<const uint8_t*>(src[i]->src), src[i]->rows,
+                           src[i]->rows_per_group > 0 ? src[i]->rows_per_group : 1, src[i]->group_stride,
+                           src[i]->row_stride, rows[i]->packed,
+                           mode == kL2Bf16 ? reinterpret_cast<__bf16*>(rows[i]->narrow) : nullptr,
+                           rows[i]->norms, mode == kL2Bf16 ? rows[i]->acc0 : nullptr,
+                           train ? scalars + kScalarNormMax : nullptr, scalars + kScalarAllMax};
+        n.set[i] = NarrowSet{rows[i]->packed, rows[i]->norms, src[i]->rows,
+                             reinterpret_cast<_Float16*>(rows[i]->narrow), rows[i]->res,
+                             train ? rows[i]->acc0 : nullptr, train ? scalars + kScalarResMax : nullptr};
+    }
+    a.blocks0 = n.blocks0 = blocks0;
+    a.dim = dim;
+    a.K = n.K = K;
+    n.all_max = scalars + kScalarAllMax;
+    n.scale_out = scalars + kScalarScale2;
+    hipLaunchKernelGGL(l2_pack_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, a);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    if (mode == kL2F16) {
+        hipLaunchKernelGGL(l2_narrow_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, n);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return SFM_OK;
+}
+
+// Candidate, re-score and exhaustive passes over packed rows; writes s.knn_idx / s.knn_dist
+// [problem][rows_cap][2].  frame_rows: rows between two frames of q / t (0 for one problem).
+// The query count among the scalars is cleared here unless the caller has done so.
+int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int squared, const L2Rows& q,
+                  const L2Rows& t, size_t frame_rows, int rows_cap, const int32_t* d_counts, int nq_uniform,
+                  int nt_uniform, const int32_t* d_pairs, int n_problems, const L2Scratch& s,
                   bool clear_todo) {
+    int32_t* todo_count = reinterpret_cast<int32_t*>(s.scalars + kScalarTodoCount);
+    const int narrow_floats = mode == kL2F16 ? plan.K / 2 : plan.K;   // floats of a narrow row
     L2Args a{};
-    a.q_base = q_base;
-    a.t_base = t_base;
-    a.t_norms = t_norms;
-    a.frame_floats = frame_floats;
+    a.q_base = mode == kL2F32 ? q.packed : q.narrow;
+    a.t_base = mode == kL2F32 ? t.packed : t.narrow;
+    a.t_norms = t.norms;
+    a.t_acc0 = t.acc0;
+    a.narrow_scale = s.scalars + kScalarScale2;
+    a.frame_floats = frame_rows * (mode == kL2F32 ? plan.K : narrow_floats);
     a.rows_cap = rows_cap;
     a.counts = d_counts;
     a.nq_uniform = nq_uniform;
@@ -1097,24 +1306,18 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     const long grid = (long)a.n_groups * a.blocks_per_group;
     if (grid <= 0) return SFM_OK;
     if (grid > 0x7fffffffL) return set_error(ctx, SFM_E_INVALID, "knn launch too large");
-    if (clear_todo) SFM_HIP_CHECK(ctx, hipMemsetAsync(s.todo_count, 0, sizeof(int32_t), ctx->stream));
-    // q_split / t_split: the rows split into bfloat16 halves (same row pitch), or null
-    const bool bf16 = q_split && t_split;
-    if (bf16) {
-        a.q_base = q_split;
-        a.t_base = t_split;
-    }
+    if (clear_todo) SFM_HIP_CHECK(ctx, hipMemsetAsync(todo_count, 0, sizeof(int32_t), ctx->stream));
     if (plan.K == 64)
-        SFM_RETURN_IF((launch_candidates<64, 2>(ctx, a, grid, bf16)));
+        SFM_RETURN_IF((launch_candidates<64, 2>(ctx, a, grid, mode)));
     else if (plan.K == 128)
-        SFM_RETURN_IF((launch_candidates<128, 2>(ctx, a, grid, bf16)));
+        SFM_RETURN_IF((launch_candidates<128, 2>(ctx, a, grid, mode)));
     else
-        SFM_RETURN_IF((launch_candidates<256, 1>(ctx, a, grid, bf16)));
+        SFM_RETURN_IF((launch_candidates<256, 1>(ctx, a, grid, mode)));
 
     RescoreArgs r{};
-    r.q_base = q_base;
-    r.t_base = t_base;
-    r.frame_floats = frame_floats;
+    r.q_base = q.packed;
+    r.t_base = t.packed;
+    r.frame_floats = frame_rows * plan.K;
     r.rows_cap = rows_cap;
     r.counts = d_counts;
     r.nq_uniform = nq_uniform;
@@ -1127,19 +1330,25 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     r.cand = s.cand;
     r.cand_key = s.cand_key;
     r.cand_third = s.cand_third;
-    r.q_norms = q_norms;
-    r.t_norm_max = s.norm_max;
-    // bfloat16 pass: three times the accumulation steps, 4 * 2^-16 of the norms left out by the
-    // split, and the position tag in a key's five low bits (below 2^-18 of a key that is at
-    // most twice the norms: 2^-17, counted as 2^-16)
-    // either pass: the lane number in the six low bits of a key when the re-score pass ranks
-    // the candidates (below 2^-17 of the key, 2^-16 of the norms)
-    r.key_error = (bf16 ? (12.0 * plan.K + 64.0) * (double)FLT_EPSILON + 5.0 / 65536.0
-                        : (4.0 * plan.K + 64.0) * (double)FLT_EPSILON) + 1.0 / 65536.0;
+    r.q_norms = q.norms;
+    r.t_norm_max = s.scalars + kScalarNormMax;
+    r.q_res = mode == kL2F16 ? q.res : nullptr;
+    r.t_res_max = s.scalars + kScalarResMax;
+    // Per pass: roundings of the norms, of the accumulation steps (fp32: K, fp16: K exact
+    // products, bfloat16: 3 K) and of the sequential sum, counted four per product.  bfloat16:
+    // 4 * 2^-16 of the norms left out by the split.  Narrow passes: the position tag in a key's
+    // five low bits (below 2^-18 of a key that is at most twice the norms: 2^-17, counted as
+    // 2^-16).  Every pass: the lane number in the six low bits of a key when the re-score pass
+    // ranks the candidates (2^-16 of the norms).  The fp16 pass adds its measured rounding of
+    // the rows per query (l2_rescore_kernel).
+    const double eps = (double)FLT_EPSILON, tag = 1.0 / 65536.0;
+    r.key_error = mode == kL2F32   ? (4.0 * plan.K + 64.0) * eps + tag
+                  : mode == kL2F16 ? (4.0 * plan.K + 64.0) * eps + 2.0 * tag
+                                   : (12.0 * plan.K + 64.0) * eps + 6.0 * tag;
     r.force_exhaustive = l2_force_exhaustive() ? 1 : 0;
     r.knn_idx = s.knn_idx;
     r.knn_dist = s.knn_dist;
-    r.todo_count = s.todo_count;
+    r.todo_count = todo_count;
     r.todo = s.todo;
     r.stat_exhaustive = ctx->stats;
     const int nq_max = d_counts ? rows_cap : nq_uniform;
@@ -1161,23 +1370,6 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, int dim, int squared, const 
     return SFM_OK;
 }
 
-// One launch for up to two sets of rows (a set of zero rows is skipped).
-int l2_pack(sfm_ctx* ctx, const PackSet& s0, const PackSet& s1, int dim, int K) {
-    const int rows_per_block = (kBlock / 64) * kPackRowsPerWave;
-    PackArgs a;
-    a.set[0] = s0;
-    a.set[1] = s1;
-    a.blocks0 = (s0.rows + rows_per_block - 1) / rows_per_block;
-    a.dim = dim;
-    a.K = K;
-    const int blocks = a.blocks0 + (s1.rows + rows_per_block - 1) / rows_per_block;
-    if (blocks <= 0) return SFM_OK;
-    KernelTimer timer(ctx, KID_L2_PACK);
-    hipLaunchKernelGGL(l2_pack_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, a);
-    SFM_HIP_CHECK(ctx, hipGetLastError());
-    return SFM_OK;
-}
-
 }  // namespace
 
 int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_stride,
@@ -1192,56 +1384,41 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
         return set_error(ctx, SFM_E_UNSUPPORTED, "float descriptors above 256 dimensions unsupported");
     const int K = plan.K;
     const int rows_cap = nq > nt ? nq : nt;
-    Carver sz(nullptr);
+    L2Rows q, t;
     L2Scratch sc;
-    sz.take<float>((size_t)nq * K);
-    sz.take<float>((size_t)(nt > 0 ? nt : 1) * K);
-    sz.take<float>((size_t)rows_cap);
-    sz.take<float>((size_t)rows_cap);
-    sz.take<float>((size_t)nq * K);
-    sz.take<float>((size_t)(nt > 0 ? nt : 1) * K);
+    Carver sz(nullptr);
+    l2_rows_carve(sz, (size_t)(nq > 0 ? nq : 1), K, &q);
+    l2_rows_carve(sz, (size_t)(nt > 0 ? nt : 1), K, &t);
     l2_scratch_carve(sz, plan, rows_cap, 1, &sc);
     void* ws;
     SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
     Carver c(ws);
-    float* qp = c.take<float>((size_t)nq * K);
-    float* tp = c.take<float>((size_t)(nt > 0 ? nt : 1) * K);
-    float* qn = c.take<float>((size_t)rows_cap);
-    float* tn = c.take<float>((size_t)rows_cap);
-    float* qs = c.take<float>((size_t)nq * K);
-    float* ts = c.take<float>((size_t)(nt > 0 ? nt : 1) * K);
+    l2_rows_carve(c, (size_t)(nq > 0 ? nq : 1), K, &q);
+    l2_rows_carve(c, (size_t)(nt > 0 ? nt : 1), K, &t);
     l2_scratch_carve(c, plan, rows_cap, 1, &sc);
     // results go straight to the caller's arrays: one problem, so [q][2] is their layout
     sc.knn_idx = d_idx;
     sc.knn_dist = d_dist;
-    static_assert(sizeof(float) == sizeof(int32_t), "norm_max and todo_count are cleared together");
     SFM_HIP_CHECK(ctx, hipMemsetAsync(ctx->stats, 0, sizeof(int32_t), ctx->stream));
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(sc.norm_max, 0, 2 * sizeof(float), ctx->stream));
-    const bool bf16 = l2_use_bf16();
-    const PackSet qset{reinterpret_cast<const uint8_t*>(d_q), nq, nq > 0 ? nq : 1, 0, q_stride, qp,
-                       bf16 ? reinterpret_cast<__bf16*>(qs) : nullptr, qn, nullptr};
-    const PackSet tset{reinterpret_cast<const uint8_t*>(d_t), nt, nt > 0 ? nt : 1, 0, t_stride, tp,
-                       bf16 ? reinterpret_cast<__bf16*>(ts) : nullptr, tn, sc.norm_max};
-    SFM_RETURN_IF(l2_pack(ctx, qset, tset, dim, K));
-    SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, qp, tp, bf16 ? qs : nullptr, bf16 ? ts : nullptr, qn, tn,
-                                0, rows_cap, nullptr, nq, nt, nullptr, 1, sc, false));
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(sc.scalars, 0, 4 * sizeof(float), ctx->stream));
+    const L2Mode mode = l2_mode();
+    SFM_RETURN_IF(l2_pack(ctx, mode, L2Source{d_q, nq, nq, 0, q_stride}, q, L2Source{d_t, nt, nt, 0, t_stride}, t,
+                          false, dim, K, sc.scalars));
+    SFM_RETURN_IF(l2_knn_packed(ctx, plan, mode, dim, squared, q, t, 0, rows_cap, nullptr, nq, nt, nullptr, 1, sc,
+                                false));
     return SFM_OK;
 }
 
 namespace {
 struct L2PairBuffers {
-    float* packed;
-    float* split;
-    float* norms;
+    L2Rows rows;
     L2Scratch sc;
     int32_t* best;
     float* best_dist;
 };
 void l2_pairs_carve(Carver& c, const L2Plan& plan, int n_frames, int rows, int n_pairs,
                     L2PairBuffers* b) {
-    b->packed = c.take<float>((size_t)n_frames * rows * plan.K);
-    b->split = c.take<float>((size_t)n_frames * rows * plan.K);
-    b->norms = c.take<float>((size_t)n_frames * rows);
+    l2_rows_carve(c, (size_t)n_frames * rows, plan.K, &b->rows);
     const size_t nprob = 2 * (size_t)n_pairs;
     l2_scratch_carve(c, plan, rows, nprob, &b->sc);
     b->best = c.take<int32_t>(nprob * rows);
@@ -1260,7 +1437,7 @@ size_t l2_match_pairs_workspace(int n_frames, int rows_per_frame, int dim, int n
     return c.total();
 }
 
-// Every frame is repacked (zero-padded to K floats, norms computed, split) on each call.
+// Every frame is repacked (zero-padded to K floats, norms computed, narrowed) on each call.
 int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_frames,
                         size_t frame_stride, int rows_per_frame, const int32_t* d_counts, int dim,
                         const int32_t* d_pairs, int n_pairs, float ratio, sfm_dmatch* d_matches,
@@ -1281,20 +1458,19 @@ int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_fr
     Carver c(ws);
     l2_pairs_carve(c, plan, n_frames, rows_per_frame, chunk, &b);
     SFM_HIP_CHECK(ctx, hipMemsetAsync(ctx->stats, 0, sizeof(int32_t), ctx->stream));
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.sc.norm_max, 0, sizeof(float), ctx->stream));
-    const bool bf16 = l2_use_bf16();
-    // every frame in one launch; rows beyond a frame's count are packed too (they are never read)
-    const PackSet frames{reinterpret_cast<const uint8_t*>(d_desc), n_frames * rows_per_frame, rows_per_frame,
-                         frame_stride, (size_t)dim * 4, b.packed,
-                         bf16 ? reinterpret_cast<__bf16*>(b.split) : nullptr, b.norms, b.sc.norm_max};
-    SFM_RETURN_IF(l2_pack(ctx, frames, PackSet{}, dim, plan.K));
-    const float* split = bf16 ? b.split : nullptr;
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.sc.scalars, 0, 4 * sizeof(float), ctx->stream));
+    const L2Mode mode = l2_mode();
+    // every frame in one launch, each serving as query and as train set; rows beyond a frame's
+    // count are packed too (they are never read)
+    SFM_RETURN_IF(l2_pack(ctx, mode, L2Source{d_desc, n_frames * rows_per_frame, rows_per_frame, frame_stride,
+                                              (size_t)dim * 4},
+                          b.rows, L2Source{nullptr, 0, 1, 0, 0}, b.rows, true, dim, plan.K, b.sc.scalars));
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
         const int np = chunk < n_pairs - p0 ? chunk : n_pairs - p0;
         const int32_t* pairs = d_pairs + 2 * (size_t)p0;
-        SFM_RETURN_IF(l2_knn_packed(ctx, plan, dim, squared, b.packed, b.packed, split, split, b.norms, b.norms,
-                                    (size_t)rows_per_frame * plan.K, rows_per_frame, d_counts,
-                                    rows_per_frame, rows_per_frame, pairs, 2 * np, b.sc, true));
+        SFM_RETURN_IF(l2_knn_packed(ctx, plan, mode, dim, squared, b.rows, b.rows, (size_t)rows_per_frame,
+                                    rows_per_frame, d_counts, rows_per_frame, rows_per_frame, pairs, 2 * np,
+                                    b.sc, true));
         SFM_RETURN_IF(launch_ratio_cross_knn(ctx, b.sc.knn_idx, b.sc.knn_dist, rows_per_frame, d_counts,
                                              rows_per_frame, pairs, np, ratio, b.best, b.best_dist,
                                              d_matches + (size_t)p0 * cap, cap,

@@ -228,27 +228,29 @@ def test_l2_zero_rows_and_extreme_magnitudes(ctx, oracle, scale):
 
 @pytest.mark.parametrize("dim", [32, 64, 128, 100])
 @pytest.mark.parametrize("integer", [True, False])
-def test_l2_both_matrix_core_passes(ctx, oracle, monkeypatch, dim, integer):
-    """The candidate pass runs on the bfloat16 matrix cores by default (every float split in a
-    high and a low bfloat16 half) and on the fp32 ones under SFM_L2_MFMA=f32.  Either way the
-    answer is the oracle's, and the wider error bound of the split form sends only a few more
-    queries to the exhaustive pass."""
+def test_l2_every_matrix_core_pass(ctx, oracle, monkeypatch, dim, integer):
+    """The candidate pass runs on the fp16 matrix cores by default (fp16 copies of the rows, the
+    rounding measured per row and added to the proof's bound), on the bfloat16 ones under
+    SFM_L2_MFMA=bf16 (every float split in a high and a low half) and on the fp32 ones under
+    SFM_L2_MFMA=f32.  Whichever it is, the answer is the oracle's, and the wider error bounds of
+    the narrow forms send only a few more queries to the exhaustive pass."""
     from sfm_amd import capi, synth
 
     q, t = synth.float_descriptors(900, 5003, dim=dim, seed=5 + dim, integer=integer)
     if integer:
-        q *= 37.0                                       # large magnitudes: a wide low half
+        q *= 37.0                                       # beyond the integers fp16 holds exactly
         t *= 37.0
     t[4000] = t[11]
     oidx, odist = oracle.knn2_l2(q, t, squared=True)
     counts = {}
-    for mode in ("bf16", "f32"):
+    for mode in ("f16", "bf16", "f32"):
         monkeypatch.setenv("SFM_L2_MFMA", mode)
         idx, dist = ctx.knn2(capi.NORM_L2SQR, q, t)
         counts[mode] = ctx.l2_exhaustive_count()
         np.testing.assert_array_equal(idx, oidx)
         np.testing.assert_array_equal(dist, odist)
     assert counts["f32"] <= counts["bf16"] <= counts["f32"] + 45
+    assert counts["f32"] <= counts["f16"] <= counts["f32"] + 90
 
 
 @pytest.mark.parametrize("integer", [True, False])
