@@ -340,34 +340,39 @@ __device__ __forceinline__ floatx16 narrow_mfma(halfx8 a, halfx8 b, floatx16 c) 
 // What is left out, ql.tl and the bits below xl, is below 4 * 2^-16 (||q||^2 + ||t||^2); the
 // re-score pass widens its error bound by that much, so the final result is still the exact
 // sequential one.  Layout and staging are those of the fp32 kernel: a split row is 2 K bfloat16
-// = K floats wide, upper halves first.  A wave owns one 32-query column block (NT = 1) so that
-// two waves fit a SIMD: one wave issues a vector instruction every six cycles at best, two
+// = K floats wide, upper halves first.  A wave owns one 32-query column block (NT = 1) and two
+// waves share a SIMD: one wave issues a vector instruction every six cycles at best, two
 // interleave, and the fold -- four instructions per key -- runs underneath the matrix
-// instructions of the next tile.  (With 64 queries per wave and one wave per SIMD the same fold
-// left the matrix pipe idle half of the time.)
+// instructions of the next tile.
 //
-// F16: the narrow rows are single fp16 copies x * s of the floats, s a power of two common to
-// all rows that brings the largest below 2^15 (l2_narrow_kernel), and q.t is one
+// F16 (the default): the narrow rows are single fp16 copies x * s of the floats, s a power of
+// two common to all rows that brings the largest below 2^15 (l2_narrow_kernel), and q.t is one
 // v_mfma_f32_32x32x16_f16 contraction -- a third of the matrix work on rows half as wide.  What
 // the rounding to eleven bits leaves out is bounded per query by the norms of the rows'
 // residuals x - fp16(x s) / s, which l2_narrow_kernel measures (Cauchy-Schwarz; zero for
 // integer-valued descriptors up to 2048), and the re-score pass adds that bound to E.  The
 // accumulators and the running lists then hold keys times s^2; the lists are scaled back when
-// they are written out.
+// they are written out.  With a third of the MFMAs the fragment reads set the pace (a wave's
+// ds_read_b128 keeps the LDS pipe 16 cycles: 64 bytes a cycle per CU), so a wave owns two
+// column blocks (NT = 2: a fragment feeds two MFMAs) in workgroups of four waves, two of them
+// resident per CU.
 template <int K, int NT, int WAVES, bool F16>
-__global__ __launch_bounds__(64 * WAVES) void l2_candidates_narrow_kernel(L2Args a) {
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(F16 ? 2 : 1)))
+void l2_candidates_narrow_kernel(L2Args a) {
     typedef typename NarrowFragment<F16>::type frag;
     constexpr int kRowFloats = F16 ? K / 2 : K;      // a narrow row in floats
     constexpr int kChunksPerRow = kRowFloats / 4;    // 16-byte chunks of a narrow row
     constexpr int kSwizzle = kChunksPerRow >= 16 ? 15 : kChunksPerRow - 1;
     constexpr int kTerms = F16 ? 1 : 3;              // contractions per step
     constexpr int kTileFloats = kTileRows * kRowFloats;
+    constexpr int kGroup = 1;   // tiles staged (and waited for) together
     constexpr int kQPerWave = 32 * NT;
     constexpr int kQPerBlock = WAVES * kQPerWave;
     static_assert(kChunksPerRow % WAVES == 0, "the waves share the staging of a tile evenly");
     constexpr int kSteps = K / 16;                   // contraction steps of 16 dimensions
-    __shared__ __attribute__((aligned(16))) float lds[2 * kTileFloats + 2 * kTileRows];
-    float* norm_lds = lds + 2 * kTileFloats;
+    __shared__ __attribute__((aligned(16))) float lds[2 * kGroup * (kTileFloats + kTileRows)];
+    float* norm_lds = lds + 2 * kGroup * kTileFloats;
+    static_assert(kGroup * kTileRows <= 64 * WAVES, "a thread per row stages the start values");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -433,12 +438,13 @@ __global__ __launch_bounds__(64 * WAVES) void l2_candidates_narrow_kernel(L2Args
     const int t_end = min(nt, t_begin + chunk);
     const int ntiles = t_end > t_begin ? (t_end - t_begin + kTileRows - 1) / kTileRows : 0;
 
-    auto stage = [&](int k, int buf) {
-        const int tbase = t_begin + k * kTileRows;
-        float* dst = lds + buf * kTileFloats;
+    // group g of kGroup tiles into buffer buf
+    auto stage = [&](int g, int buf) {
+        const int tbase = t_begin + g * kGroup * kTileRows;
+        float* dst = lds + buf * kGroup * kTileFloats;
 #pragma unroll
-        for (int it = 0; it < kChunksPerRow / WAVES; ++it) {
-            const int instr = wave * (kChunksPerRow / WAVES) + it;
+        for (int it = 0; it < kGroup * kChunksPerRow / WAVES; ++it) {
+            const int instr = wave * (kGroup * kChunksPerRow / WAVES) + it;
             const int p = instr * 64 + lane;
             const int row = p / kChunksPerRow, cpos = p % kChunksPerRow;
             const int c = cpos ^ (row & kSwizzle);
@@ -446,11 +452,11 @@ __global__ __launch_bounds__(64 * WAVES) void l2_candidates_narrow_kernel(L2Args
             trow = trow < nt ? trow : nt - 1;  // clamped rows are masked by a norm of kNoRow
             glds16(trows + (size_t)trow * kRowFloats + c * 4, dst + instr * 256);
         }
-        if (tid < kTileRows) {
+        if (tid < kGroup * kTileRows) {
             const int trow = tbase + tid;
             // q.t changes nothing in kNoRowAcc (its ulp is 2^103): a masked row's key is never
             // below a best
-            norm_lds[buf * kTileRows + tid] = trow < t_end ? tacc0[trow] : kNoRowAcc;
+            norm_lds[buf * kGroup * kTileRows + tid] = trow < t_end ? tacc0[trow] : kNoRowAcc;
         }
     };
 
@@ -511,10 +517,10 @@ __global__ __launch_bounds__(64 * WAVES) void l2_candidates_narrow_kernel(L2Args
     constexpr int kFoldUnits = kMfmas - 3 * NT;    // the last 3 NT carry the merges
     static_assert(kFoldUnits > 0, "the fold needs room beside the merges");
     auto tile_step = [&](floatx16 (&accC)[2][NT], const floatx16 (&accF)[2][NT], int k) {
-        const int buf = k & 1;
-        if (k + 1 < ntiles) stage(k + 1, buf ^ 1);
-        const float* tile = lds + buf * kTileFloats;
-        const float* nrm = norm_lds + buf * kTileRows;
+        const int group = k / kGroup, sub = k % kGroup, buf = group & 1;
+        if (sub == 0 && (group + 1) * kGroup < ntiles) stage(group + 1, buf ^ 1);
+        const float* tile = lds + (buf * kGroup + sub) * kTileFloats;
+        const float* nrm = norm_lds + (buf * kGroup + sub) * kTileRows;
         const int tbase_prev = t_begin + (k - 1) * kTileRows;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(64 * WAVES) void l2_candidates_narrow_kernel(L2Args
                 al[mt] = al_next[mt];
             }
         }
-        __syncthreads();
+        if (sub == kGroup - 1) __syncthreads();   // (past the last tile nothing is read)
     };
 
     for (int k = 0; k < ntiles; k += 2) {
@@ -619,12 +625,25 @@ __global__ __launch_bounds__(64 * WAVES) void l2_candidates_narrow_kernel(L2Args
     }
 }
 
+// Raises *dst (a non-negative float, ordered like its bit pattern; NaN candidates are skipped by
+// the callers' comparisons) to the largest `v` of the workgroup, with at most one atomic.
+__device__ __forceinline__ void block_max_to(float* dst, float v) {
+    __shared__ float s_max[kBlock / 64];
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0 && dst) {
+        for (int w = 1; w < kBlock / 64; ++w) v = fmaxf(v, s_max[w]);
+        if (v > *reinterpret_cast<volatile float*>(dst)) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(v));
+    }
+}
+
 // Up to two sets of float rows (queries and train rows, or the frames of a sequence) are brought
-// into the layout of the passes in one launch: zero-padded rows of K floats, ||row||^2, the rows
-// split into 2 K bfloat16 -- the K upper halves xh = bf16(x), then the K lower halves
-// xl = bf16(x - xh), both rounded to nearest even (x - xh is exact in fp32) -- and the largest
-// norm of a set (norm_max must be zero before the launch; non-negative floats order like their
-// bit patterns; a NaN norm is skipped, its row never ranks anyway).
+// into the layout of the passes in one launch: zero-padded rows of K floats, ||row||^2, for the
+// bfloat16 pass the rows split into 2 K bfloat16 -- the K upper halves xh = bf16(x), then the K
+// lower halves xl = bf16(x - xh), both rounded to nearest even (x - xh is exact in fp32) -- and
+// the largest norm of all rows (all_max must be zero before the launch; a NaN norm is skipped,
+// its row never ranks anyway).
 struct PackSet {
     const uint8_t* src;
     int rows, rows_per_group;          // row r lies in group r / rows_per_group
@@ -633,8 +652,7 @@ struct PackSet {
     __bf16* split;                     // [rows][2 K], or null
     float* norms;                      // [rows]
     float* acc0;                       // [rows]: -||row||^2 / 2, or null
-    float* norm_max;                   // one float, or null
-    float* all_max;                    // one float shared by both sets, or null
+    float* all_max;                    // largest ||row||^2 of both sets (one float), or null
 };
 struct PackArgs {
     PackSet set[2];
@@ -700,12 +718,9 @@ __global__ __launch_bounds__(kBlock) void l2_pack_kernel(PackArgs a) {
         }
         largest = acc > largest ? acc : largest;
     }
-    // the maximum only grows: a wave whose rows do not exceed what is there leaves it alone
+    // the maximum only grows: a workgroup whose rows do not exceed what is there leaves it alone
     // (thousands of atomics on one address would take longer than the packing)
-    if (p.norm_max && lane == 0 && largest > *reinterpret_cast<volatile float*>(p.norm_max))
-        atomicMax(reinterpret_cast<unsigned*>(p.norm_max), __float_as_uint(largest));
-    if (p.all_max && lane == 0 && largest > *reinterpret_cast<volatile float*>(p.all_max))
-        atomicMax(reinterpret_cast<unsigned*>(p.all_max), __float_as_uint(largest));
+    block_max_to(p.all_max, largest);
 }
 
 // Packed rows -> single fp16 copies for the fp16 candidate pass, in one launch for up to two
@@ -794,8 +809,7 @@ __global__ __launch_bounds__(kBlock) void l2_narrow_kernel(NarrowArgs a) {
         }
         largest = res > largest ? res : largest;
     }
-    if (p.res_max && lane == 0 && largest > *reinterpret_cast<volatile float*>(p.res_max))
-        atomicMax(reinterpret_cast<unsigned*>(p.res_max), __float_as_uint(largest));
+    block_max_to(p.res_max, largest);
 }
 
 // Squared distance as the sequential float sum d += (a-b)*(a-b), the scalar order of OpenCV's
@@ -841,6 +855,7 @@ struct RescoreArgs {
     int32_t* todo_count;  // queries whose result is not proven: count, then (problem, query) pairs
     int32_t* todo;
     int32_t* stat_exhaustive;  // per-context total of such queries since the entry point began
+    unsigned long long* partial;  // exhaustive pass: best two of every (entry, slice)
 };
 
 // min(v, v of the lane the DPP control names); a lane the control leaves out keeps its own
@@ -1052,13 +1067,23 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
     }
 }
 
-// The listed queries against every train row: one workgroup per entry (grid-stride), one train
-// row per lane and step, best two by (sequential distance, train index).
+// Slices of the train rows per listed query: a short list is spread over the whole launch (one
+// workgroup takes 0.4 ms for 20 000 rows of 128), a long one gets a workgroup per query.
+__device__ __forceinline__ int exhaustive_slices(int count, int grid) {
+    return count >= grid ? 1 : min(64, grid / count);
+}
+
+// The listed queries against every train row: one workgroup per (entry, slice of the train rows)
+// (grid-stride), one train row per lane and step, best two by (sequential distance, train index)
+// into partial[item][2]; l2_exhaustive_merge_kernel joins the slices.
 __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
     __shared__ unsigned long long red[2][kBlock / 64];
     const int count = *a.todo_count;
+    if (count == 0) return;
+    const int slices = exhaustive_slices(count, gridDim.x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int e = blockIdx.x; e < count; e += gridDim.x) {
+    for (int item = blockIdx.x; item < count * slices; item += gridDim.x) {
+        const int e = item / slices, slice = item % slices;
         const int problem = a.todo[2 * (size_t)e], q = a.todo[2 * (size_t)e + 1];
         int qf = 0, tf = 0;
         if (a.pairs) {
@@ -1068,10 +1093,12 @@ __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
             tf = dir ? fa : fb;
         }
         const int nt = a.counts ? a.counts[tf] : a.nt_uniform;
+        const int per_slice = (nt + slices - 1) / slices;
+        const int t_begin = slice * per_slice, t_end = min(nt, t_begin + per_slice);
         const float* qrow = a.q_base + (size_t)qf * a.frame_floats + (size_t)q * a.K;
         const float* trows = a.t_base + (size_t)tf * a.frame_floats;
         unsigned long long m0 = ~0ull, m1 = ~0ull;
-        for (int t = threadIdx.x; t < nt; t += kBlock) {
+        for (int t = t_begin + threadIdx.x; t < t_end; t += kBlock) {
             float d = sequential_sqr(qrow, trows + (size_t)t * a.K, a.K);
             if (!a.squared) d = sqrtf(d);
             const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
@@ -1103,15 +1130,49 @@ __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
                         k1 = key;
                     }
                 }
-            const size_t o = ((size_t)problem * a.rows_cap + q) * 2;
-            const float d0 = __uint_as_float((unsigned)(k0 >> 32)), d1 = __uint_as_float((unsigned)(k1 >> 32));
-            a.knn_idx[o] = k0 == ~0ull ? -1 : (int32_t)(k0 & 0xFFFFFFFFu);
-            a.knn_idx[o + 1] = k1 == ~0ull ? -1 : (int32_t)(k1 & 0xFFFFFFFFu);
-            a.knn_dist[o] = k0 == ~0ull ? FLT_MAX : d0;
-            a.knn_dist[o + 1] = k1 == ~0ull ? FLT_MAX : d1;
+            a.partial[2 * (size_t)item] = k0;
+            a.partial[2 * (size_t)item + 1] = k1;
         }
         __syncthreads();
     }
+}
+
+// Best two of the slices of every listed query -> knn_idx / knn_dist.  `grid` is the size of the
+// l2_exhaustive_kernel launch that wrote the slices.
+__global__ void l2_exhaustive_merge_kernel(RescoreArgs a, int grid) {
+    const int count = *a.todo_count;
+    if (count == 0) return;
+    const int slices = exhaustive_slices(count, grid);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x) {
+        unsigned long long k0 = ~0ull, k1 = ~0ull;
+        for (int i = 0; i < 2 * slices; ++i) {
+            const unsigned long long key = a.partial[2 * (size_t)e * slices + i];
+            if (key < k0) {
+                k1 = k0;
+                k0 = key;
+            } else if (key < k1) {
+                k1 = key;
+            }
+        }
+        const int problem = a.todo[2 * (size_t)e], q = a.todo[2 * (size_t)e + 1];
+        const size_t o = ((size_t)problem * a.rows_cap + q) * 2;
+        const float d0 = __uint_as_float((unsigned)(k0 >> 32)), d1 = __uint_as_float((unsigned)(k1 >> 32));
+        a.knn_idx[o] = k0 == ~0ull ? -1 : (int32_t)(k0 & 0xFFFFFFFFu);
+        a.knn_idx[o + 1] = k1 == ~0ull ? -1 : (int32_t)(k1 & 0xFFFFFFFFu);
+        a.knn_dist[o] = k0 == ~0ull ? FLT_MAX : d0;
+        a.knn_dist[o + 1] = k1 == ~0ull ? FLT_MAX : d1;
+    }
+}
+
+// Which matrix cores rank the candidates.  SFM_L2_MFMA=f32 / bf16 select the other passes (a
+// measuring and testing aid, read per call); the default is the fp16 pass.
+enum L2Mode { kL2F32, kL2Bf16, kL2F16 };
+L2Mode l2_mode() {
+    const char* e = getenv("SFM_L2_MFMA");
+    if (!e) return kL2F16;
+    if (e[0] == 'f' && e[1] == '3') return kL2F32;
+    if (e[0] == 'b') return kL2Bf16;
+    return kL2F16;
 }
 
 struct L2Plan {
@@ -1133,9 +1194,11 @@ int make_l2_plan(const sfm_ctx* ctx, int dim, int nq_max, int nt_max, int n_prob
     }
     p->q_per_block = 4 * 32 * p->NT;
     p->qtiles = (nq_max + p->q_per_block - 1) / p->q_per_block;
-    // One workgroup per CU fits (register file), so the launch runs in rounds of num_cus
-    // workgroups: pick the split count (<= kMaxSplits, >= 128 train rows each) that wastes
-    // the least in the last round and in the partial last tile; ties go to fewer splits.
+    // The launch runs in rounds of resident workgroups (one per CU, two of the fp16 pass): pick
+    // the split count (<= kMaxSplits, >= 128 train rows each) that wastes the least in the last
+    // round of num_cus and in the partial last tile; ties go to fewer splits.  (Counting two
+    // workgroups per CU for the fp16 pass picks 12 splits for 20 000 rows instead of 16: no
+    // faster, and with fewer candidate lists the odd query fails the proof.)
     const long base = (long)p->qtiles * n_problems;
     int splits = 1;
     double best_eff = -1.0;
@@ -1156,24 +1219,13 @@ int make_l2_plan(const sfm_ctx* ctx, int dim, int nq_max, int nt_max, int n_prob
     return SFM_OK;
 }
 
-// Which matrix cores rank the candidates.  SFM_L2_MFMA=f32 / bf16 select the other passes (a
-// measuring and testing aid, read per call); the default is the fp16 pass.
-enum L2Mode { kL2F32, kL2Bf16, kL2F16 };
-L2Mode l2_mode() {
-    const char* e = getenv("SFM_L2_MFMA");
-    if (!e) return kL2F16;
-    if (e[0] == 'f' && e[1] == '3') return kL2F32;
-    if (e[0] == 'b') return kL2Bf16;
-    return kL2F16;
-}
-
 template <int K, int NT>
 int launch_candidates(sfm_ctx* ctx, const L2Args& a, long grid, L2Mode mode) {
     KernelTimer timer(ctx, KID_L2_CANDIDATES);
     // narrow passes: the same queries per workgroup, one 32-query column block per wave
-    if (mode == kL2F16)
-        hipLaunchKernelGGL((l2_candidates_narrow_kernel<K, 1, 4 * NT, true>), dim3((unsigned)grid),
-                           dim3(64 * 4 * NT), 0, ctx->stream, a);
+    if (mode == kL2F16)   // 64 queries per wave: half the fragment reads, two workgroups per CU
+        hipLaunchKernelGGL((l2_candidates_narrow_kernel<K, NT, 4, true>), dim3((unsigned)grid),
+                           dim3(64 * 4), 0, ctx->stream, a);
     else if (mode == kL2Bf16)
         hipLaunchKernelGGL((l2_candidates_narrow_kernel<K, 1, 4 * NT, false>), dim3((unsigned)grid),
                            dim3(64 * 4 * NT), 0, ctx->stream, a);
@@ -1191,17 +1243,20 @@ struct L2Scratch {
     float* cand_third;   // [problems][splits][rows_cap][2]
     float* scalars;      // kScalar* below
     int32_t* todo;       // [problems][rows_cap][2]
+    unsigned long long* partial;  // [max(problems x rows_cap, kExhaustiveGrid)][2]
     int32_t* knn_idx;    // [problems][rows_cap][2]
     float* knn_dist;
 };
+constexpr int kExhaustiveGrid = 1024;
 // scalars: the first four are cleared before the rows are packed
-enum { kScalarNormMax = 0, kScalarTodoCount, kScalarAllMax, kScalarResMax, kScalarScale2, kScalarUnscale2, kScalars };
+enum { kScalarSpare = 0, kScalarTodoCount, kScalarAllMax, kScalarResMax, kScalarScale2, kScalarUnscale2, kScalars };
 void l2_scratch_carve(Carver& c, const L2Plan& plan, int rows_cap, size_t n_problems, L2Scratch* s) {
     s->cand = c.take<int32_t>(n_problems * plan.splits * rows_cap * 4);
     s->cand_key = c.take<float>(n_problems * plan.splits * rows_cap * 4);
     s->cand_third = c.take<float>(n_problems * plan.splits * rows_cap * 2);
     s->scalars = c.take<float>(kScalars);
     s->todo = c.take<int32_t>(n_problems * rows_cap * 2);
+    s->partial = c.take<unsigned long long>(std::max<size_t>(n_problems * rows_cap, kExhaustiveGrid) * 2);
     s->knn_idx = c.take<int32_t>(n_problems * rows_cap * 2);
     s->knn_dist = c.take<float>(n_problems * rows_cap * 2);
 }
@@ -1255,8 +1310,7 @@ int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, const L2Rows& rows0
                            src[i]->rows_per_group > 0 ? src[i]->rows_per_group : 1, src[i]->group_stride,
                            src[i]->row_stride, rows[i]->packed,
                            mode == kL2Bf16 ? reinterpret_cast<__bf16*>(rows[i]->narrow) : nullptr,
-                           rows[i]->norms, mode == kL2Bf16 ? rows[i]->acc0 : nullptr,
-                           train ? scalars + kScalarNormMax : nullptr, scalars + kScalarAllMax};
+                           rows[i]->norms, mode == kL2Bf16 ? rows[i]->acc0 : nullptr, scalars + kScalarAllMax};
         n.set[i] = NarrowSet{rows[i]->packed, rows[i]->norms, src[i]->rows,
                              reinterpret_cast<_Float16*>(rows[i]->narrow), rows[i]->res,
                              train ? rows[i]->acc0 : nullptr, train ? scalars + kScalarResMax : nullptr};
@@ -1331,7 +1385,7 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int sq
     r.cand_key = s.cand_key;
     r.cand_third = s.cand_third;
     r.q_norms = q.norms;
-    r.t_norm_max = s.scalars + kScalarNormMax;
+    r.t_norm_max = s.scalars + kScalarAllMax;   // the queries' norms are in it too: a bound all the same
     r.q_res = mode == kL2F16 ? q.res : nullptr;
     r.t_res_max = s.scalars + kScalarResMax;
     // Per pass: roundings of the norms, of the accumulation steps (fp32: K, fp16: K exact
@@ -1351,6 +1405,7 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int sq
     r.todo_count = todo_count;
     r.todo = s.todo;
     r.stat_exhaustive = ctx->stats;
+    r.partial = s.partial;
     const int nq_max = d_counts ? rows_cap : nq_uniform;
     const dim3 rgrid((nq_max + kBlock / 64 - 1) / (kBlock / 64), n_problems);
     {
@@ -1365,7 +1420,9 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int sq
     }
     // the listed queries (normally none: the workgroups read a zero count and leave)
     KernelTimer timer(ctx, KID_L2_EXHAUSTIVE);
-    hipLaunchKernelGGL(l2_exhaustive_kernel, dim3(4 * ctx->num_cus), dim3(kBlock), 0, ctx->stream, r);
+    hipLaunchKernelGGL(l2_exhaustive_kernel, dim3(kExhaustiveGrid), dim3(kBlock), 0, ctx->stream, r);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(l2_exhaustive_merge_kernel, dim3(64), dim3(256), 0, ctx->stream, r, kExhaustiveGrid);
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
 }
