@@ -5,8 +5,8 @@
 // for the "BRUTEFORCE" and "BRUTEFORCE_SL2" matcher types (:111, :115).
 //
 // Passes.
-//   0. Packing (l2_pack_kernel): rows zero-padded to K floats, ||row||^2, and the rows split into
-//      bfloat16 halves for pass 1.
+//   0. Packing (l2_pack_kernel, l2_narrow_kernel): rows zero-padded to K floats, ||row||^2, and
+//      narrow copies of the rows for pass 1.
 //   1. Candidate pass (MFMA).  The ranking key ||q - t||^2 - ||q||^2 = ||t||^2 - 2 q.t is formed as
 //      a dense contraction: the train tile is the A operand (rows = train), the query tile the
 //      B operand (columns = queries), so each lane's accumulator registers hold 16 train
@@ -16,9 +16,10 @@
 //      source address so that the ds_read_b128 fragment reads are conflict-free); the
 //      accumulators start at the norm term, so the accumulator is the ranking key when the
 //      k-loop ends.  Every (lane half, train split) keeps its own best two, which are written
-//      out as candidates.  By default the contraction runs on the bfloat16 matrix cores, every
-//      float split into two bfloat16 halves (l2_candidates_bf16_kernel, sixteen times the rate);
-//      SFM_L2_MFMA=f32 selects v_mfma_f32_32x32x2_f32 on unsplit rows (l2_candidates_kernel).
+//      out as candidates.  By default the contraction runs on the fp16 matrix cores, sixteen
+//      times the rate, over fp16 copies of the rows (l2_candidates_narrow_kernel); SFM_L2_MFMA
+//      selects a three-product bfloat16 split (bf16) or v_mfma_f32_32x32x2_f32 on the floats
+//      themselves (f32, l2_candidates_kernel).
 //      The key only ranks: its rounding is covered by the proof of pass 2.
 //   2. Re-score pass.  For the eight candidates of a query with the smallest ranking
 //      keys the squared distance is recomputed as the sequential float sum
