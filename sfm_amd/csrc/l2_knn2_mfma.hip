@@ -659,6 +659,7 @@ struct PackArgs {
     PackSet set[2];
     int blocks0;   // workgroups of set 0; the rest serve set 1
     int dim, K;
+    int32_t* clear[2];   // counters of later kernels that this launch zeroes (or null)
 };
 constexpr int kPackRowsPerWave = 8;
 
@@ -669,6 +670,7 @@ __global__ __launch_bounds__(kBlock) void l2_pack_kernel(PackArgs a) {
     const int lane = threadIdx.x & 63;
     const int row0 = (block * (kBlock / 64) + (threadIdx.x >> 6)) * kPackRowsPerWave;
     const int K = a.K;
+    if (blockIdx.x == 0 && threadIdx.x < 2 && a.clear[threadIdx.x]) *a.clear[threadIdx.x] = 0;
     // A lane takes element pairs lane and lane + 64 of a row (K <= 256: at most 128 pairs).  All
     // the loads of the wave's rows go out before the first value is used.
     typedef float floatx2 __attribute__((ext_vector_type(2)));
@@ -1249,7 +1251,7 @@ struct L2Scratch {
     float* knn_dist;
 };
 constexpr int kExhaustiveGrid = 1024;
-// scalars: the first four are cleared before the rows are packed
+// scalars: the query count and the largest norm are cleared before the rows are packed
 enum { kScalarSpare = 0, kScalarTodoCount, kScalarAllMax, kScalarResMax, kScalarScale2, kScalarUnscale2, kScalars };
 void l2_scratch_carve(Carver& c, const L2Plan& plan, int rows_cap, size_t n_problems, L2Scratch* s) {
     s->cand = c.take<int32_t>(n_problems * plan.splits * rows_cap * 4);
@@ -1296,12 +1298,17 @@ struct L2Source {
 };
 int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, const L2Rows& rows0, const L2Source& src1,
             const L2Rows& rows1, bool set0_is_train, int dim, int K, float* scalars) {
+    // scalars[kScalarAllMax] must be zero; the launch clears the residual maximum and the
+    // context's count of exhaustive queries for the kernels after it
     const int rows_per_block = (kBlock / 64) * kPackRowsPerWave;
     const L2Source* src[2] = {&src0, &src1};
     const L2Rows* rows[2] = {&rows0, &rows1};
     const int blocks0 = (src0.rows + rows_per_block - 1) / rows_per_block;
     const int blocks = blocks0 + (src1.rows + rows_per_block - 1) / rows_per_block;
-    if (blocks <= 0) return SFM_OK;
+    if (blocks <= 0) {   // nothing to pack: only the count of exhaustive queries is reset
+        SFM_HIP_CHECK(ctx, hipMemsetAsync(ctx->stats, 0, sizeof(int32_t), ctx->stream));
+        return SFM_OK;
+    }
     KernelTimer timer(ctx, KID_L2_PACK);
     PackArgs a{};
     NarrowArgs n{};
@@ -1317,6 +1324,8 @@ int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, const L2Rows& rows0
                              train ? rows[i]->acc0 : nullptr, train ? scalars + kScalarResMax : nullptr};
     }
     a.blocks0 = n.blocks0 = blocks0;
+    a.clear[0] = reinterpret_cast<int32_t*>(scalars + kScalarResMax);
+    a.clear[1] = ctx->stats;
     a.dim = dim;
     a.K = n.K = K;
     n.all_max = scalars + kScalarAllMax;
@@ -1457,8 +1466,7 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
     // results go straight to the caller's arrays: one problem, so [q][2] is their layout
     sc.knn_idx = d_idx;
     sc.knn_dist = d_dist;
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(ctx->stats, 0, sizeof(int32_t), ctx->stream));
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(sc.scalars, 0, 4 * sizeof(float), ctx->stream));
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(sc.scalars + kScalarTodoCount, 0, 2 * sizeof(float), ctx->stream));
     const L2Mode mode = l2_mode();
     SFM_RETURN_IF(l2_pack(ctx, mode, L2Source{d_q, nq, nq, 0, q_stride}, q, L2Source{d_t, nt, nt, 0, t_stride}, t,
                           false, dim, K, sc.scalars));
@@ -1515,8 +1523,7 @@ int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_fr
     SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
     Carver c(ws);
     l2_pairs_carve(c, plan, n_frames, rows_per_frame, chunk, &b);
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(ctx->stats, 0, sizeof(int32_t), ctx->stream));
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.sc.scalars, 0, 4 * sizeof(float), ctx->stream));
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.sc.scalars + kScalarTodoCount, 0, 2 * sizeof(float), ctx->stream));
     const L2Mode mode = l2_mode();
     // every frame in one launch, each serving as query and as train set; rows beyond a frame's
     // count are packed too (they are never read)
