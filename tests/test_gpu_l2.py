@@ -253,6 +253,50 @@ def test_l2_every_matrix_core_pass(ctx, oracle, monkeypatch, dim, integer):
     assert counts["f32"] <= counts["f16"] <= counts["f32"] + 90
 
 
+@pytest.mark.parametrize("dim,rows,counts", [(128, 900, [900, 257, 640, 2, 513]), (64, 700, [700, 65, 300, 699, 128]),
+                                             (200, 500, [500, 130, 1, 300, 499])])
+@pytest.mark.parametrize("mode", ["f16", "bf16", "f32"])
+def test_l2_match_pairs_ragged(ctx, oracle, monkeypatch, dim, rows, counts, mode):
+    """Every ordered pair of five float-descriptor frames with very different row counts in one
+    call (all frames packed once, each serving as query and as train set), against the
+    oracle's cross-checked ratio matching, through each candidate pass."""
+    import torch
+
+    from sfm_amd import capi
+
+    monkeypatch.setenv("SFM_L2_MFMA", mode)
+    rng = np.random.default_rng(7 + dim)
+    n_frames = len(counts)
+    base = rng.standard_normal((rows, dim)).astype(np.float32)
+    frames = []
+    for f in range(n_frames):
+        fr = base + 0.15 * rng.standard_normal((rows, dim)).astype(np.float32)
+        fresh = rng.random(rows) < 0.3
+        fr[fresh] = rng.standard_normal((int(fresh.sum()), dim)).astype(np.float32)
+        frames.append(fr[rng.permutation(rows)] * np.float32(3.0 ** f))   # frames of different scale
+    stack = np.stack(frames)
+    counts = np.array(counts, np.int32)
+    pairs = np.array([(i, j) for i in range(n_frames) for j in range(n_frames) if i != j], np.int32)
+    dev = torch.device("cuda:0")
+    d_desc, d_counts, d_pairs = (torch.from_numpy(x).to(dev) for x in (stack, counts, pairs))
+    cap = rows
+    d_matches = torch.zeros((len(pairs), cap, 4), dtype=torch.int32, device=dev)
+    d_mc = torch.zeros(len(pairs), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.match_pairs_dev(capi.NORM_L2, d_desc, n_frames, rows * dim * 4, rows, d_counts, dim, d_pairs,
+                        len(pairs), 0.8, d_matches, cap, d_mc)
+    ctx.synchronize()
+    mc = d_mc.cpu().numpy()
+    m = d_matches.cpu().numpy().view(capi.DMATCH_DTYPE).reshape(len(pairs), cap)
+    total = 0
+    for p, (i, j) in enumerate(pairs):
+        want = oracle.robust_matches(oracle.NORM_L2, stack[i][: counts[i]], stack[j][: counts[j]], 0.8)
+        assert mc[p] == len(want), (i, j)
+        assert _tuples(m[p][: mc[p]]) == _tuples(want), (i, j)
+        total += len(want)
+    assert total > 100
+
+
 @pytest.mark.parametrize("integer", [True, False])
 def test_l2_full_size_20000x20000x128(ctx, oracle, integer):
     """The float-matching configuration at the size it is quoted on (20 000 x 20 000 x 128, both
