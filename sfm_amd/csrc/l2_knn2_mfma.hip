@@ -649,7 +649,7 @@ struct PackSet {
     const uint8_t* src;
     int rows, rows_per_group;          // row r lies in group r / rows_per_group
     size_t group_stride, row_stride;   // bytes
-    float* dst;                        // [rows][K]
+    float* dst;                        // [rows][K], or null (the rows are used in place)
     __bf16* split;                     // [rows][2 K], or null
     float* norms;                      // [rows]
     float* acc0;                       // [rows]: -||row||^2 / 2, or null
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void l2_pack_kernel(PackArgs a) {
             const int j = 2 * (lane + 64 * i);
             if (j < K) {
                 const floatx2 x = v[r][i];
-                *reinterpret_cast<floatx2*>(p.dst + (size_t)row * K + j) = x;
+                if (p.dst) *reinterpret_cast<floatx2*>(p.dst + (size_t)row * K + j) = x;
                 if (p.split) {
                     bf16x2 h, l;
                     h.x = (__bf16)x.x;
@@ -1296,13 +1296,23 @@ struct L2Source {
     int rows, rows_per_group;
     size_t group_stride, row_stride;
 };
-int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, const L2Rows& rows0, const L2Source& src1,
-            const L2Rows& rows1, bool set0_is_train, int dim, int K, float* scalars) {
+int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, L2Rows* rows0, const L2Source& src1,
+            L2Rows* rows1, bool set0_is_train, int dim, int K, float* scalars) {
     // scalars[kScalarAllMax] must be zero; the launch clears the residual maximum and the
     // context's count of exhaustive queries for the kernels after it
     const int rows_per_block = (kBlock / 64) * kPackRowsPerWave;
     const L2Source* src[2] = {&src0, &src1};
-    const L2Rows* rows[2] = {&rows0, &rows1};
+    L2Rows* rows[2] = {rows0, rows1};
+    // Rows that already are what the packed copy would be -- K floats wide, back to back,
+    // 16-byte aligned -- are read in place by every pass: no copy is written.
+    for (int i = 0; i < 2; ++i) {
+        const L2Source& sr = *src[i];
+        const bool one_group = sr.rows <= sr.rows_per_group;
+        if (sr.rows > 0 && dim == K && sr.row_stride == (size_t)K * 4 &&
+            (one_group || sr.group_stride == (size_t)sr.rows_per_group * K * 4) &&
+            (reinterpret_cast<uintptr_t>(sr.src) & 15) == 0)
+            rows[i]->packed = nullptr;
+    }
     const int blocks0 = (src0.rows + rows_per_block - 1) / rows_per_block;
     const int blocks = blocks0 + (src1.rows + rows_per_block - 1) / rows_per_block;
     if (blocks <= 0) {   // nothing to pack: only the count of exhaustive queries is reset
@@ -1316,9 +1326,10 @@ int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, const L2Rows& rows0
         const bool train = i == 1 || set0_is_train;
         a.set[i] = PackSet{static_cast<const uint8_t*>(src[i]->src), src[i]->rows,
                            src[i]->rows_per_group > 0 ? src[i]->rows_per_group : 1, src[i]->group_stride,
-                           src[i]->row_stride, rows[i]->packed,
+                           src[i]->row_stride, rows[i]->packed,   // (null: no copy)
                            mode == kL2Bf16 ? reinterpret_cast<__bf16*>(rows[i]->narrow) : nullptr,
                            rows[i]->norms, mode == kL2Bf16 ? rows[i]->acc0 : nullptr, scalars + kScalarAllMax};
+        if (!rows[i]->packed) rows[i]->packed = const_cast<float*>(static_cast<const float*>(src[i]->src));
         n.set[i] = NarrowSet{rows[i]->packed, rows[i]->norms, src[i]->rows,
                              reinterpret_cast<_Float16*>(rows[i]->narrow), rows[i]->res,
                              train ? rows[i]->acc0 : nullptr, train ? scalars + kScalarResMax : nullptr};
@@ -1468,7 +1479,7 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
     sc.knn_dist = d_dist;
     SFM_HIP_CHECK(ctx, hipMemsetAsync(sc.scalars + kScalarTodoCount, 0, 2 * sizeof(float), ctx->stream));
     const L2Mode mode = l2_mode();
-    SFM_RETURN_IF(l2_pack(ctx, mode, L2Source{d_q, nq, nq, 0, q_stride}, q, L2Source{d_t, nt, nt, 0, t_stride}, t,
+    SFM_RETURN_IF(l2_pack(ctx, mode, L2Source{d_q, nq, nq, 0, q_stride}, &q, L2Source{d_t, nt, nt, 0, t_stride}, &t,
                           false, dim, K, sc.scalars));
     SFM_RETURN_IF(l2_knn_packed(ctx, plan, mode, dim, squared, q, t, 0, rows_cap, nullptr, nq, nt, nullptr, 1, sc,
                                 false));
@@ -1527,9 +1538,10 @@ int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_fr
     const L2Mode mode = l2_mode();
     // every frame in one launch, each serving as query and as train set; rows beyond a frame's
     // count are packed too (they are never read)
+    L2Rows spare = b.rows;
     SFM_RETURN_IF(l2_pack(ctx, mode, L2Source{d_desc, n_frames * rows_per_frame, rows_per_frame, frame_stride,
                                               (size_t)dim * 4},
-                          b.rows, L2Source{nullptr, 0, 1, 0, 0}, b.rows, true, dim, plan.K, b.sc.scalars));
+                          &b.rows, L2Source{nullptr, 0, 1, 0, 0}, &spare, true, dim, plan.K, b.sc.scalars));
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
         const int np = chunk < n_pairs - p0 ? chunk : n_pairs - p0;
         const int32_t* pairs = d_pairs + 2 * (size_t)p0;
