@@ -729,10 +729,11 @@ __global__ __launch_bounds__(kBlock) void l2_pack_kernel(PackArgs a) {
 // Packed rows -> single fp16 copies for the fp16 candidate pass, in one launch for up to two
 // sets.  s = 2^shift is common to all rows: the largest norm times s stays below 2^15, so no
 // element leaves the fp16 range, and products of scaled elements are exact in the matrix
-// pipe's fp32.  Per row: the fp16 row fp16(x s) (round to nearest even), the norm of what the
+// pipe's fp32.  Per row: the fp16 row fp16(x s) (round to nearest even); the norm of what the
 // rounding left out, ||x - fp16(x s) / s|| (the differences are exact in fp32; the sum is
-// rounded up by a part in a thousand), the accumulator start value -||x||^2 s^2 / 2; per set the
-// largest residual norm (res_max zero before the launch).  scale_out: s^2 and 1 / s^2.
+// rounded up by a part in a thousand, and by the most that a pipe reading fp16 denormals as
+// zero could drop); the accumulator start value -||x||^2 s^2 / 2.  Per set the largest residual
+// norm (res_max zero before the launch).  scale_out: s^2 and 1 / s^2.
 struct NarrowSet {
     const float* packed;   // [rows][K]
     const float* norms;    // [rows]
@@ -805,7 +806,9 @@ __global__ __launch_bounds__(kBlock) void l2_narrow_kernel(NarrowArgs a) {
             }
         }
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        const float res = sqrtf(acc) * 1.001f;
+        // (+ what a matrix pipe that reads fp16 denormals as zero would drop: up to 2^-14 / s
+        // in each of the K elements)
+        const float res = (sqrtf(acc) + sqrtf((float)K) * ldexpf(inv_s, -14)) * 1.001f;
         if (lane == 0) {
             p.res[row] = res;
             if (p.acc0) p.acc0[row] = -0.5f * p.norms[row] * s2;
