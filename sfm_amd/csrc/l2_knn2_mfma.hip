@@ -336,7 +336,7 @@ __device__ __forceinline__ floatx16 narrow_mfma(halfx8 a, halfx8 b, floatx16 c) 
 
 // The candidate pass on the bfloat16 matrix cores (sixteen times the rate of the fp32 ones).
 // Every float x of the packed rows is split into xh + xl, two bfloat16 values that carry its
-// upper sixteen significant bits (l2_split_kernel), and q.t is formed as qh.th + qh.tl + ql.th
+// upper sixteen significant bits (l2_pack_kernel), and q.t is formed as qh.th + qh.tl + ql.th
 // -- three v_mfma_f32_32x32x16_bf16 contractions with exact products and fp32 accumulation.
 // What is left out, ql.tl and the bits below xl, is below 4 * 2^-16 (||q||^2 + ||t||^2); the
 // re-score pass widens its error bound by that much, so the final result is still the exact
@@ -851,7 +851,7 @@ struct RescoreArgs {
     const float* cand_key;
     const float* cand_third;
     const float* q_norms;  // ||q||^2 per packed row, rows_cap per frame
-    const float* t_norm_max;  // largest ||t||^2 of any packed row (one float)
+    const float* t_norm_max;  // at least the largest ||t||^2 of any packed row (one float)
     double key_error;  // bound on |ranking key + ||q||^2 - sequential distance| / (||q||^2 + max ||t||^2)
     const float* q_res;      // fp16 pass: residual norm of every query row (rows_cap per frame), or null
     const float* t_res_max;  // fp16 pass: largest residual norm of a train row
