@@ -818,24 +818,6 @@ __global__ __launch_bounds__(kBlock) void l2_narrow_kernel(NarrowArgs a) {
     block_max_to(p.res_max, largest);
 }
 
-// Squared distance as the sequential float sum d += (a-b)*(a-b), the scalar order of OpenCV's
-// normL2Sqr.  Rows are zero-padded to K floats and (0 - 0)^2 adds an exact zero, so running
-// to K changes nothing.
-__device__ __forceinline__ float sequential_sqr(const float* qrow, const float* trow, int K) {
-    const floatx4* q4 = reinterpret_cast<const floatx4*>(qrow);
-    const floatx4* t4 = reinterpret_cast<const floatx4*>(trow);
-    float d = 0.f;
-    for (int j = 0; j < K / 4; ++j) {
-        const floatx4 qa = q4[j], ta = t4[j];
-        const float v0 = qa.x - ta.x, v1 = qa.y - ta.y, v2 = qa.z - ta.z, v3 = qa.w - ta.w;
-        d += v0 * v0;
-        d += v1 * v1;
-        d += v2 * v2;
-        d += v3 * v3;
-    }
-    return d;
-}
-
 struct RescoreArgs {
     const float* q_base;
     const float* t_base;
@@ -1073,73 +1055,155 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
     }
 }
 
-// Slices of the train rows per listed query: a short list is spread over the whole launch (one
-// workgroup takes 0.4 ms for 20 000 rows of 128), a long one gets a workgroup per query.
-__device__ __forceinline__ int exhaustive_slices(int count, int grid) {
-    return count >= grid ? 1 : min(64, grid / count);
+// The exhaustive pass takes the listed queries in groups of kExQueries whose rows sit in LDS:
+// a train row is read once per group, not once per query.
+constexpr int kExQueries = 8;    // queries per group
+constexpr int kExRows = 4;       // train rows a thread works on at a time
+
+// Slices of the train rows per group: a short list is spread over the whole launch (one
+// workgroup alone takes 0.4 ms for 20 000 rows of 128), a long one gets a workgroup per group.
+__device__ __forceinline__ int exhaustive_slices(int groups, int grid) {
+    return groups >= grid ? 1 : min(64, grid / groups);
 }
 
-// The listed queries against every train row: one workgroup per (entry, slice of the train rows)
-// (grid-stride), one train row per lane and step, best two by (sequential distance, train index)
-// into partial[item][2]; l2_exhaustive_merge_kernel joins the slices.
+// The listed queries against every train row: one workgroup per (group of entries, slice of the
+// train rows) (grid-stride).  A thread forms the sequential distances of kExRows train rows to
+// the group's queries, element by element in the order of OpenCV's normL2Sqr, and keeps the
+// best two per query by (distance, train index) -- it meets its rows in ascending order, so a
+// strict comparison leaves the lower index in front; the workgroup's best two go to
+// partial[entry][slice][2], and l2_exhaustive_merge_kernel joins the slices.  K = 64 KPL.
+template <int KPL>
 __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
-    __shared__ unsigned long long red[2][kBlock / 64];
+    constexpr int K = 64 * KPL;
+    __shared__ __attribute__((aligned(16))) float s_q[kExQueries][K];
+    __shared__ unsigned long long s_red[kBlock / 64][kExQueries][2];
     const int count = *a.todo_count;
     if (count == 0) return;
-    const int slices = exhaustive_slices(count, gridDim.x);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int item = blockIdx.x; item < count * slices; item += gridDim.x) {
-        const int e = item / slices, slice = item % slices;
-        const int problem = a.todo[2 * (size_t)e], q = a.todo[2 * (size_t)e + 1];
-        int qf = 0, tf = 0;
-        if (a.pairs) {
-            const int gp = problem >> 1, dir = problem & 1;
-            const int fa = a.pairs[2 * gp], fb = a.pairs[2 * gp + 1];
-            qf = dir ? fb : fa;
-            tf = dir ? fa : fb;
-        }
-        const int nt = a.counts ? a.counts[tf] : a.nt_uniform;
-        const int per_slice = (nt + slices - 1) / slices;
-        const int t_begin = slice * per_slice, t_end = min(nt, t_begin + per_slice);
-        const float* qrow = a.q_base + (size_t)qf * a.frame_floats + (size_t)q * a.K;
-        const float* trows = a.t_base + (size_t)tf * a.frame_floats;
-        unsigned long long m0 = ~0ull, m1 = ~0ull;
-        for (int t = t_begin + threadIdx.x; t < t_end; t += kBlock) {
-            float d = sequential_sqr(qrow, trows + (size_t)t * a.K, a.K);
-            if (!a.squared) d = sqrtf(d);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)t;
-            if (key < m0) {
-                m1 = m0;
-                m0 = key;
-            } else if (key < m1) {
-                m1 = key;
+    const int groups = (count + kExQueries - 1) / kExQueries;
+    const int slices = exhaustive_slices(groups, gridDim.x);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int item = blockIdx.x; item < groups * slices; item += gridDim.x) {
+        const int e0 = (item / slices) * kExQueries, slice = item % slices;
+        const int ne = min(kExQueries, count - e0);
+        // entries of one problem share the train rows: take them run by run
+        for (int r0 = 0; r0 < ne;) {
+            const int problem = a.todo[2 * (size_t)(e0 + r0)];
+            int r1 = r0 + 1;
+            while (r1 < ne && a.todo[2 * (size_t)(e0 + r1)] == problem) ++r1;
+            const int nrun = r1 - r0;
+            int qf = 0, tf = 0;
+            if (a.pairs) {
+                const int gp = problem >> 1, dir = problem & 1;
+                const int fa = a.pairs[2 * gp], fb = a.pairs[2 * gp + 1];
+                qf = dir ? fb : fa;
+                tf = dir ? fa : fb;
             }
-        }
-        // best two of the workgroup: the smallest, then the smallest of what is left
-        const unsigned long long w0 = wave_min_u64(m0);
-        const unsigned long long mine = m0 == w0 ? m1 : m0;  // keys are distinct (they hold the index)
-        const unsigned long long w1 = wave_min_u64(mine);
-        if (lane == 0) {
-            red[0][wave] = w0;
-            red[1][wave] = w1;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long k0 = ~0ull, k1 = ~0ull;
-            for (int w = 0; w < kBlock / 64; ++w)
-                for (int r = 0; r < 2; ++r) {
-                    const unsigned long long key = red[r][w];
-                    if (key < k0) {
-                        k1 = k0;
-                        k0 = key;
-                    } else if (key < k1) {
-                        k1 = key;
+            const int nt = a.counts ? a.counts[tf] : a.nt_uniform;
+            const int per_slice = (nt + slices - 1) / slices;
+            const int t_begin = slice * per_slice, t_end = min(nt, t_begin + per_slice);
+            const float* trows = a.t_base + (size_t)tf * a.frame_floats;
+            __syncthreads();   // the rows of the run before are done with
+            for (int i = tid; i < kExQueries * (K / 4); i += kBlock) {
+                const int qq = i / (K / 4), j4 = i % (K / 4);
+                floatx4 v = {0.f, 0.f, 0.f, 0.f};
+                if (qq < nrun) {
+                    const int q = a.todo[2 * (size_t)(e0 + r0 + qq) + 1];
+                    v = *reinterpret_cast<const floatx4*>(a.q_base + (size_t)qf * a.frame_floats + (size_t)q * K +
+                                                          4 * j4);
+                }
+                *reinterpret_cast<floatx4*>(&s_q[qq][4 * j4]) = v;
+            }
+            __syncthreads();
+            float bd0[kExQueries], bd1[kExQueries];
+            int bi0[kExQueries], bi1[kExQueries];
+#pragma unroll
+            for (int qq = 0; qq < kExQueries; ++qq) {
+                bd0[qq] = bd1[qq] = INFINITY;
+                bi0[qq] = bi1[qq] = -1;
+            }
+            for (int t0 = t_begin + tid; t0 < t_end; t0 += kExRows * kBlock) {
+                float d[kExRows][kExQueries];
+#pragma unroll
+                for (int r = 0; r < kExRows; ++r)
+#pragma unroll
+                    for (int qq = 0; qq < kExQueries; ++qq) d[r][qq] = 0.f;
+                const floatx4* trow[kExRows];
+#pragma unroll
+                for (int r = 0; r < kExRows; ++r)   // a row past the slice re-reads the last one
+                    trow[r] = reinterpret_cast<const floatx4*>(trows + (size_t)min(t0 + r * kBlock, t_end - 1) * K);
+#pragma unroll 2
+                for (int j4 = 0; j4 < K / 4; ++j4) {
+                    floatx4 tv[kExRows];
+#pragma unroll
+                    for (int r = 0; r < kExRows; ++r) tv[r] = trow[r][j4];
+#pragma unroll
+                    for (int qq = 0; qq < kExQueries; ++qq) {
+                        const floatx4 qv = *reinterpret_cast<const floatx4*>(&s_q[qq][4 * j4]);
+#pragma unroll
+                        for (int r = 0; r < kExRows; ++r) {
+                            const float v0 = qv.x - tv[r].x, v1 = qv.y - tv[r].y, v2 = qv.z - tv[r].z,
+                                        v3 = qv.w - tv[r].w;
+                            d[r][qq] += v0 * v0;
+                            d[r][qq] += v1 * v1;
+                            d[r][qq] += v2 * v2;
+                            d[r][qq] += v3 * v3;
+                        }
                     }
                 }
-            a.partial[2 * (size_t)item] = k0;
-            a.partial[2 * (size_t)item + 1] = k1;
+#pragma unroll
+                for (int r = 0; r < kExRows; ++r) {
+                    const int t = t0 + r * kBlock;
+                    if (t < t_end) {
+#pragma unroll
+                        for (int qq = 0; qq < kExQueries; ++qq) {
+                            const float dd = a.squared ? d[r][qq] : sqrtf(d[r][qq]);
+                            if (dd < bd0[qq]) {
+                                bd1[qq] = bd0[qq];
+                                bi1[qq] = bi0[qq];
+                                bd0[qq] = dd;
+                                bi0[qq] = t;
+                            } else if (dd < bd1[qq]) {
+                                bd1[qq] = dd;
+                                bi1[qq] = t;
+                            }
+                        }
+                    }
+                }
+            }
+            // best two of the workgroup per query: the smallest key, then the smallest of what is
+            // left (keys are distinct: they hold the index)
+#pragma unroll
+            for (int qq = 0; qq < kExQueries; ++qq) {
+                const unsigned long long k0 =
+                    bi0[qq] < 0 ? ~0ull : ((unsigned long long)__float_as_uint(bd0[qq]) << 32) | (unsigned)bi0[qq];
+                const unsigned long long k1 =
+                    bi1[qq] < 0 ? ~0ull : ((unsigned long long)__float_as_uint(bd1[qq]) << 32) | (unsigned)bi1[qq];
+                const unsigned long long w0 = wave_min_u64(k0);
+                const unsigned long long w1 = wave_min_u64(k0 == w0 ? k1 : k0);
+                if (lane == 0) {
+                    s_red[wave][qq][0] = w0;
+                    s_red[wave][qq][1] = w1;
+                }
+            }
+            __syncthreads();
+            if (tid < nrun) {
+                unsigned long long k0 = ~0ull, k1 = ~0ull;
+                for (int w = 0; w < kBlock / 64; ++w)
+                    for (int r = 0; r < 2; ++r) {
+                        const unsigned long long key = s_red[w][tid][r];
+                        if (key < k0) {
+                            k1 = k0;
+                            k0 = key;
+                        } else if (key < k1) {
+                            k1 = key;
+                        }
+                    }
+                const size_t o = 2 * ((size_t)(e0 + r0 + tid) * slices + slice);
+                a.partial[o] = k0;
+                a.partial[o + 1] = k1;
+            }
+            r0 = r1;
         }
-        __syncthreads();
     }
 }
 
@@ -1148,7 +1212,7 @@ __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
 __global__ void l2_exhaustive_merge_kernel(RescoreArgs a, int grid) {
     const int count = *a.todo_count;
     if (count == 0) return;
-    const int slices = exhaustive_slices(count, grid);
+    const int slices = exhaustive_slices((count + kExQueries - 1) / kExQueries, grid);
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x) {
         unsigned long long k0 = ~0ull, k1 = ~0ull;
         for (int i = 0; i < 2 * slices; ++i) {
@@ -1249,7 +1313,7 @@ struct L2Scratch {
     float* cand_third;   // [problems][splits][rows_cap][2]
     float* scalars;      // kScalar* below
     int32_t* todo;       // [problems][rows_cap][2]
-    unsigned long long* partial;  // [max(problems x rows_cap, kExhaustiveGrid)][2]
+    unsigned long long* partial;  // [max(problems x rows_cap, kExQueries x kExhaustiveGrid)][2]
     int32_t* knn_idx;    // [problems][rows_cap][2]
     float* knn_dist;
 };
@@ -1262,7 +1326,8 @@ void l2_scratch_carve(Carver& c, const L2Plan& plan, int rows_cap, size_t n_prob
     s->cand_third = c.take<float>(n_problems * plan.splits * rows_cap * 2);
     s->scalars = c.take<float>(kScalars);
     s->todo = c.take<int32_t>(n_problems * rows_cap * 2);
-    s->partial = c.take<unsigned long long>(std::max<size_t>(n_problems * rows_cap, kExhaustiveGrid) * 2);
+    s->partial = c.take<unsigned long long>(
+        std::max<size_t>(n_problems * rows_cap, (size_t)kExQueries * kExhaustiveGrid) * 2);
     s->knn_idx = c.take<int32_t>(n_problems * rows_cap * 2);
     s->knn_dist = c.take<float>(n_problems * rows_cap * 2);
 }
@@ -1444,7 +1509,12 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int sq
     }
     // the listed queries (normally none: the workgroups read a zero count and leave)
     KernelTimer timer(ctx, KID_L2_EXHAUSTIVE);
-    hipLaunchKernelGGL(l2_exhaustive_kernel, dim3(kExhaustiveGrid), dim3(kBlock), 0, ctx->stream, r);
+    if (plan.K == 64)
+        hipLaunchKernelGGL(l2_exhaustive_kernel<1>, dim3(kExhaustiveGrid), dim3(kBlock), 0, ctx->stream, r);
+    else if (plan.K == 128)
+        hipLaunchKernelGGL(l2_exhaustive_kernel<2>, dim3(kExhaustiveGrid), dim3(kBlock), 0, ctx->stream, r);
+    else
+        hipLaunchKernelGGL(l2_exhaustive_kernel<4>, dim3(kExhaustiveGrid), dim3(kBlock), 0, ctx->stream, r);
     SFM_HIP_CHECK(ctx, hipGetLastError());
     hipLaunchKernelGGL(l2_exhaustive_merge_kernel, dim3(64), dim3(256), 0, ctx->stream, r, kExhaustiveGrid);
     SFM_HIP_CHECK(ctx, hipGetLastError());
