@@ -366,7 +366,7 @@ void l2_candidates_narrow_kernel(L2Args a) {
     constexpr int kSwizzle = kChunksPerRow >= 16 ? 15 : kChunksPerRow - 1;
     constexpr int kTerms = F16 ? 1 : 3;              // contractions per step
     constexpr int kTileFloats = kTileRows * kRowFloats;
-    constexpr int kGroup = 1;   // tiles staged (and waited for) together
+    constexpr int kGroup = 1;   // tiles staged (and waited for) together; four measured no faster
     constexpr int kQPerWave = 32 * NT;
     constexpr int kQPerBlock = WAVES * kQPerWave;
     static_assert(kChunksPerRow % WAVES == 0, "the waves share the staging of a tile evenly");
