@@ -719,8 +719,11 @@ int run_corners(sfm_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_
         SFM_HIP_CHECK(ctx, hipGetLastError());
         // about 32 waves per CU over the whole batch, at least 32 workgroups per image
         const unsigned per_image = (unsigned)std::min(std::max(ctx->num_cus * 32 / n_images, 32), 1024);
+        // the open candidates thin out round by round (a few hundred are left after the fourth);
+        // the late rounds, empty more often than not, are smaller launches
         for (int r = 0; r < kSelectRounds; ++r) {
-            hipLaunchKernelGGL(corner_select_kernel, dim3(per_image, n), dim3(256), 0, s, a, r);
+            const unsigned blocks = r < 2 ? per_image : std::max(per_image / (r < 4 ? 2u : 8u), 32u);
+            hipLaunchKernelGGL(corner_select_kernel, dim3(blocks, n), dim3(256), 0, s, a, r);
             SFM_HIP_CHECK(ctx, hipGetLastError());
         }
         hipLaunchKernelGGL(corner_settle_kernel, dim3(n), dim3(64), 0, s, a);
