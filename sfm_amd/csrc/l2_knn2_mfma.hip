@@ -654,6 +654,7 @@ struct PackSet {
     float* norms;                      // [rows]
     float* acc0;                       // [rows]: -||row||^2 / 2, or null
     float* all_max;                    // largest ||row||^2 of both sets (one float), or null
+    const int32_t* counts;             // rows in use per group, or null: the rest does not enter all_max
 };
 struct PackArgs {
     PackSet set[2];
@@ -719,7 +720,11 @@ __global__ __launch_bounds__(kBlock) void l2_pack_kernel(PackArgs a) {
             p.norms[row] = acc;
             if (p.acc0) p.acc0[row] = -0.5f * acc;
         }
-        largest = acc > largest ? acc : largest;
+        // rows past a frame's count are whatever the caller's buffer holds: they are converted
+        // like the others (nothing reads them) but must not set the scale or the error bound
+        const int group = row / p.rows_per_group;
+        const bool in_use = !p.counts || row - group * p.rows_per_group < p.counts[group];
+        largest = in_use && acc > largest ? acc : largest;
     }
     // the maximum only grows: a workgroup whose rows do not exceed what is there leaves it alone
     // (thousands of atomics on one address would take longer than the packing)
@@ -742,6 +747,8 @@ struct NarrowSet {
     float* res;            // [rows]
     float* acc0;           // [rows], or null
     float* res_max;        // one float, or null
+    int rows_per_group;    // as in PackSet
+    const int32_t* counts;
 };
 struct NarrowArgs {
     NarrowSet set[2];
@@ -813,7 +820,9 @@ __global__ __launch_bounds__(kBlock) void l2_narrow_kernel(NarrowArgs a) {
             p.res[row] = res;
             if (p.acc0) p.acc0[row] = -0.5f * p.norms[row] * s2;
         }
-        largest = res > largest ? res : largest;
+        const int group = row / p.rows_per_group;
+        const bool in_use = !p.counts || row - group * p.rows_per_group < p.counts[group];
+        largest = in_use && res > largest ? res : largest;
     }
     block_max_to(p.res_max, largest);
 }
@@ -1363,6 +1372,7 @@ struct L2Source {
     const void* src;
     int rows, rows_per_group;
     size_t group_stride, row_stride;
+    const int32_t* counts;   // rows in use per group (device), or null
 };
 int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, L2Rows* rows0, const L2Source& src1,
             L2Rows* rows1, bool set0_is_train, int dim, int K, float* scalars) {
@@ -1396,11 +1406,13 @@ int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, L2Rows* rows0, cons
                            src[i]->rows_per_group > 0 ? src[i]->rows_per_group : 1, src[i]->group_stride,
                            src[i]->row_stride, rows[i]->packed,   // (null: no copy)
                            mode == kL2Bf16 ? reinterpret_cast<__bf16*>(rows[i]->narrow) : nullptr,
-                           rows[i]->norms, mode == kL2Bf16 ? rows[i]->acc0 : nullptr, scalars + kScalarAllMax};
+                           rows[i]->norms, mode == kL2Bf16 ? rows[i]->acc0 : nullptr, scalars + kScalarAllMax,
+                           src[i]->counts};
         if (!rows[i]->packed) rows[i]->packed = const_cast<float*>(static_cast<const float*>(src[i]->src));
         n.set[i] = NarrowSet{rows[i]->packed, rows[i]->norms, src[i]->rows,
                              reinterpret_cast<_Float16*>(rows[i]->narrow), rows[i]->res,
-                             train ? rows[i]->acc0 : nullptr, train ? scalars + kScalarResMax : nullptr};
+                             train ? rows[i]->acc0 : nullptr, train ? scalars + kScalarResMax : nullptr,
+                             src[i]->rows_per_group > 0 ? src[i]->rows_per_group : 1, src[i]->counts};
     }
     a.blocks0 = n.blocks0 = blocks0;
     a.clear[0] = reinterpret_cast<int32_t*>(scalars + kScalarResMax);
@@ -1552,7 +1564,8 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
     sc.knn_dist = d_dist;
     SFM_HIP_CHECK(ctx, hipMemsetAsync(sc.scalars + kScalarTodoCount, 0, 2 * sizeof(float), ctx->stream));
     const L2Mode mode = l2_mode();
-    SFM_RETURN_IF(l2_pack(ctx, mode, L2Source{d_q, nq, nq, 0, q_stride}, &q, L2Source{d_t, nt, nt, 0, t_stride}, &t,
+    SFM_RETURN_IF(l2_pack(ctx, mode, L2Source{d_q, nq, nq, 0, q_stride, nullptr}, &q,
+                          L2Source{d_t, nt, nt, 0, t_stride, nullptr}, &t,
                           false, dim, K, sc.scalars));
     SFM_RETURN_IF(l2_knn_packed(ctx, plan, mode, dim, squared, q, t, 0, rows_cap, nullptr, nq, nt, nullptr, 1, sc,
                                 false));
@@ -1613,8 +1626,8 @@ int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_fr
     // count are packed too (they are never read)
     L2Rows spare = b.rows;
     SFM_RETURN_IF(l2_pack(ctx, mode, L2Source{d_desc, n_frames * rows_per_frame, rows_per_frame, frame_stride,
-                                              (size_t)dim * 4},
-                          &b.rows, L2Source{nullptr, 0, 1, 0, 0}, &spare, true, dim, plan.K, b.sc.scalars));
+                                              (size_t)dim * 4, d_counts},
+                          &b.rows, L2Source{nullptr, 0, 1, 0, 0, nullptr}, &spare, true, dim, plan.K, b.sc.scalars));
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
         const int np = chunk < n_pairs - p0 ? chunk : n_pairs - p0;
         const int32_t* pairs = d_pairs + 2 * (size_t)p0;
