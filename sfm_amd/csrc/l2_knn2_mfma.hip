@@ -643,8 +643,8 @@ __device__ __forceinline__ void block_max_to(float* dst, float v) {
 // into the layout of the passes in one launch: zero-padded rows of K floats, ||row||^2, for the
 // bfloat16 pass the rows split into 2 K bfloat16 -- the K upper halves xh = bf16(x), then the K
 // lower halves xl = bf16(x - xh), both rounded to nearest even (x - xh is exact in fp32) -- and
-// the largest norm of all rows (all_max must be zero before the launch; a NaN norm is skipped,
-// its row never ranks anyway).
+// the largest norm of every group of rows (a frame; the queries; the train rows), which must be
+// zero before the launch; a NaN norm is skipped, its row never ranks anyway.
 struct PackSet {
     const uint8_t* src;
     int rows, rows_per_group;          // row r lies in group r / rows_per_group
@@ -653,14 +653,16 @@ struct PackSet {
     __bf16* split;                     // [rows][2 K], or null
     float* norms;                      // [rows]
     float* acc0;                       // [rows]: -||row||^2 / 2, or null
-    float* all_max;                    // largest ||row||^2 of both sets (one float), or null
-    const int32_t* counts;             // rows in use per group, or null: the rest does not enter all_max
+    const int32_t* counts;             // rows in use per group, or null: the rest does not enter the maxima
+    float* group_max;                  // [groups] largest ||row||^2 of every group
 };
 struct PackArgs {
     PackSet set[2];
     int blocks0;   // workgroups of set 0; the rest serve set 1
     int dim, K;
     int32_t* clear[2];   // counters of later kernels that this launch zeroes (or null)
+    float* clear_res;    // and the groups' largest residual norms
+    int n_clear_res;
 };
 constexpr int kPackRowsPerWave = 8;
 
@@ -670,8 +672,12 @@ __global__ __launch_bounds__(kBlock) void l2_pack_kernel(PackArgs a) {
     const int block = second ? blockIdx.x - a.blocks0 : blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int row0 = (block * (kBlock / 64) + (threadIdx.x >> 6)) * kPackRowsPerWave;
+    const int block_group = min(block * (kBlock / 64) * kPackRowsPerWave, p.rows - 1) / p.rows_per_group;
     const int K = a.K;
-    if (blockIdx.x == 0 && threadIdx.x < 2 && a.clear[threadIdx.x]) *a.clear[threadIdx.x] = 0;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 2 && a.clear[threadIdx.x]) *a.clear[threadIdx.x] = 0;
+        for (int i = threadIdx.x; i < a.n_clear_res; i += kBlock) a.clear_res[i] = 0.f;
+    }
     // A lane takes element pairs lane and lane + 64 of a row (K <= 256: at most 128 pairs).  All
     // the loads of the wave's rows go out before the first value is used.
     typedef float floatx2 __attribute__((ext_vector_type(2)));
@@ -724,11 +730,16 @@ __global__ __launch_bounds__(kBlock) void l2_pack_kernel(PackArgs a) {
         // like the others (nothing reads them) but must not set the scale or the error bound
         const int group = row / p.rows_per_group;
         const bool in_use = !p.counts || row - group * p.rows_per_group < p.counts[group];
-        largest = in_use && acc > largest ? acc : largest;
+        // the workgroup raises the maximum of its first row's group with one atomic; a row of
+        // another group (a workgroup across a frame boundary) does so for itself
+        if (group == block_group)
+            largest = in_use && acc > largest ? acc : largest;
+        else if (lane == 0 && in_use && acc > *reinterpret_cast<volatile float*>(p.group_max + group))
+            atomicMax(reinterpret_cast<unsigned*>(p.group_max + group), __float_as_uint(acc));
     }
     // the maximum only grows: a workgroup whose rows do not exceed what is there leaves it alone
     // (thousands of atomics on one address would take longer than the packing)
-    block_max_to(p.all_max, largest);
+    block_max_to(p.group_max + block_group, largest);
 }
 
 // Packed rows -> single fp16 copies for the fp16 candidate pass, in one launch for up to two
@@ -746,7 +757,7 @@ struct NarrowSet {
     _Float16* half;        // [rows][K]
     float* res;            // [rows]
     float* acc0;           // [rows], or null
-    float* res_max;        // one float, or null
+    float* group_res;      // [groups] largest residual norm of every group
     int rows_per_group;    // as in PackSet
     const int32_t* counts;
 };
@@ -754,7 +765,8 @@ struct NarrowArgs {
     NarrowSet set[2];
     int blocks0;
     int K;
-    const float* all_max;  // largest ||row||^2 of both sets
+    const float* group_max;  // [n_groups] largest ||row||^2 of every group of both sets
+    int n_groups;
     float* scale_out;
 };
 
@@ -766,9 +778,13 @@ __global__ __launch_bounds__(kBlock) void l2_narrow_kernel(NarrowArgs a) {
     const int block = second ? blockIdx.x - a.blocks0 : blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int row0 = (block * (kBlock / 64) + (threadIdx.x >> 6)) * kPackRowsPerWave;
+    const int block_group = min(block * (kBlock / 64) * kPackRowsPerWave, p.rows - 1) / p.rows_per_group;
     const int K = a.K;
-    // sqrt(m) < 2^e, so |x| s < 2^15 for every element x of every row
-    const float m = *a.all_max;
+    // m: the largest ||row||^2 of all groups; sqrt(m) < 2^e, so |x| s < 2^15 for every element x
+    // of every row
+    float m = 0.f;
+    for (int g = lane; g < a.n_groups; g += 64) m = fmaxf(m, a.group_max[g]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     int shift = 0;
     if (m > 0.f && m < INFINITY) {
         int ex;
@@ -822,9 +838,12 @@ __global__ __launch_bounds__(kBlock) void l2_narrow_kernel(NarrowArgs a) {
         }
         const int group = row / p.rows_per_group;
         const bool in_use = !p.counts || row - group * p.rows_per_group < p.counts[group];
-        largest = in_use && res > largest ? res : largest;
+        if (group == block_group)
+            largest = in_use && res > largest ? res : largest;
+        else if (lane == 0 && in_use && res > *reinterpret_cast<volatile float*>(p.group_res + group))
+            atomicMax(reinterpret_cast<unsigned*>(p.group_res + group), __float_as_uint(res));
     }
-    block_max_to(p.res_max, largest);
+    block_max_to(p.group_res + block_group, largest);
 }
 
 struct RescoreArgs {
@@ -842,10 +861,10 @@ struct RescoreArgs {
     const float* cand_key;
     const float* cand_third;
     const float* q_norms;  // ||q||^2 per packed row, rows_cap per frame
-    const float* t_norm_max;  // at least the largest ||t||^2 of any packed row (one float)
+    const float* t_norm_max;  // per train frame: the largest ||t||^2 of its rows in use
     double key_error;  // bound on |ranking key + ||q||^2 - sequential distance| / (||q||^2 + max ||t||^2)
     const float* q_res;      // fp16 pass: residual norm of every query row (rows_cap per frame), or null
-    const float* t_res_max;  // fp16 pass: largest residual norm of a train row
+    const float* t_res_max;  // fp16 pass, per train frame: the largest residual norm of its rows in use
     int force_exhaustive;
     int32_t* knn_idx;  // [problem][rows_cap][2]
     float* knn_dist;
@@ -1033,12 +1052,12 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
             const unsigned u = ord ^ ((ord >> 31) ? 0x80000000u : 0xFFFFFFFFu);
             const double T = (double)__uint_as_float(u);
             const double qn = (double)a.q_norms[(size_t)qf * a.rows_cap + q];
-            const double tmax = (double)*a.t_norm_max;
+            const double tmax = (double)a.t_norm_max[tf];
             double E = a.key_error * (qn + tmax);
             if (a.q_res) {
                 // fp16 pass: |q.t - q'.t'| <= |q - q'| |t| + |q| |t - t'| + |q - q'| |t - t'| for
                 // the rounded rows q', t' (Cauchy-Schwarz), twice that in the key
-                const double rq = (double)a.q_res[(size_t)qf * a.rows_cap + q], rt = (double)*a.t_res_max;
+                const double rq = (double)a.q_res[(size_t)qf * a.rows_cap + q], rt = (double)a.t_res_max[tf];
                 E += 2.002 * (rq * sqrt(tmax) + sqrt(qn) * rt + rq * rt);
             }
             // NORM_L2 ranks by the rounded square root, which maps neighbouring sums to one
@@ -1320,25 +1339,37 @@ struct L2Scratch {
     int32_t* cand;       // [problems][splits][rows_cap][4]
     float* cand_key;     // same layout
     float* cand_third;   // [problems][splits][rows_cap][2]
-    float* scalars;      // kScalar* below
+    float* scalars;      // see below
+    int groups;          // groups of rows (frames; queries and train rows) with maxima of their own
     int32_t* todo;       // [problems][rows_cap][2]
     unsigned long long* partial;  // [max(problems x rows_cap, kExQueries x kExhaustiveGrid)][2]
     int32_t* knn_idx;    // [problems][rows_cap][2]
     float* knn_dist;
 };
 constexpr int kExhaustiveGrid = 1024;
-// scalars: the query count and the largest norm are cleared before the rows are packed
-enum { kScalarSpare = 0, kScalarTodoCount, kScalarAllMax, kScalarResMax, kScalarScale2, kScalarUnscale2, kScalars };
-void l2_scratch_carve(Carver& c, const L2Plan& plan, int rows_cap, size_t n_problems, L2Scratch* s) {
+// scalars: [spare][count of listed queries][spare][largest norm per group ...]
+// [largest residual per group ...][s^2][1 / s^2].  The count and the groups' largest norms are
+// cleared before the rows are packed (one memset).
+enum { kScalarSpare = 0, kScalarTodoCount, kScalarUnused, kScalarGroups };
+inline float* scratch_group_max(const L2Scratch& s) { return s.scalars + kScalarGroups; }
+inline float* scratch_group_res(const L2Scratch& s) { return s.scalars + kScalarGroups + s.groups; }
+inline float* scratch_scale(const L2Scratch& s) { return s.scalars + kScalarGroups + 2 * s.groups; }
+void l2_scratch_carve(Carver& c, const L2Plan& plan, int rows_cap, size_t n_problems, int groups, L2Scratch* s) {
     s->cand = c.take<int32_t>(n_problems * plan.splits * rows_cap * 4);
     s->cand_key = c.take<float>(n_problems * plan.splits * rows_cap * 4);
     s->cand_third = c.take<float>(n_problems * plan.splits * rows_cap * 2);
-    s->scalars = c.take<float>(kScalars);
+    s->groups = groups;
+    s->scalars = c.take<float>(kScalarGroups + 2 * (size_t)groups + 2);
     s->todo = c.take<int32_t>(n_problems * rows_cap * 2);
     s->partial = c.take<unsigned long long>(
         std::max<size_t>(n_problems * rows_cap, (size_t)kExQueries * kExhaustiveGrid) * 2);
     s->knn_idx = c.take<int32_t>(n_problems * rows_cap * 2);
     s->knn_dist = c.take<float>(n_problems * rows_cap * 2);
+}
+int l2_scratch_clear(sfm_ctx* ctx, const L2Scratch& s) {
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(s.scalars + kScalarTodoCount, 0, (2 + (size_t)s.groups) * sizeof(float),
+                                      ctx->stream));
+    return SFM_OK;
 }
 static_assert(sizeof(float) == sizeof(int32_t), "the query count lives among the float scalars");
 
@@ -1375,9 +1406,10 @@ struct L2Source {
     const int32_t* counts;   // rows in use per group (device), or null
 };
 int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, L2Rows* rows0, const L2Source& src1,
-            L2Rows* rows1, bool set0_is_train, int dim, int K, float* scalars) {
-    // scalars[kScalarAllMax] must be zero; the launch clears the residual maximum and the
-    // context's count of exhaustive queries for the kernels after it
+            L2Rows* rows1, bool set0_is_train, int dim, int K, const L2Scratch& sc) {
+    // after l2_scratch_clear; the launch clears the groups' residual maxima and the context's
+    // count of exhaustive queries for the kernels after it.  Groups: those of set 0, then set 1.
+    const int groups0 = src0.rows > 0 ? (src0.rows + src0.rows_per_group - 1) / src0.rows_per_group : 0;
     const int rows_per_block = (kBlock / 64) * kPackRowsPerWave;
     const L2Source* src[2] = {&src0, &src1};
     L2Rows* rows[2] = {rows0, rows1};
@@ -1406,21 +1438,24 @@ int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, L2Rows* rows0, cons
                            src[i]->rows_per_group > 0 ? src[i]->rows_per_group : 1, src[i]->group_stride,
                            src[i]->row_stride, rows[i]->packed,   // (null: no copy)
                            mode == kL2Bf16 ? reinterpret_cast<__bf16*>(rows[i]->narrow) : nullptr,
-                           rows[i]->norms, mode == kL2Bf16 ? rows[i]->acc0 : nullptr, scalars + kScalarAllMax,
-                           src[i]->counts};
+                           rows[i]->norms, mode == kL2Bf16 ? rows[i]->acc0 : nullptr, src[i]->counts,
+                           scratch_group_max(sc) + (i ? groups0 : 0)};
         if (!rows[i]->packed) rows[i]->packed = const_cast<float*>(static_cast<const float*>(src[i]->src));
         n.set[i] = NarrowSet{rows[i]->packed, rows[i]->norms, src[i]->rows,
                              reinterpret_cast<_Float16*>(rows[i]->narrow), rows[i]->res,
-                             train ? rows[i]->acc0 : nullptr, train ? scalars + kScalarResMax : nullptr,
+                             train ? rows[i]->acc0 : nullptr, scratch_group_res(sc) + (i ? groups0 : 0),
                              src[i]->rows_per_group > 0 ? src[i]->rows_per_group : 1, src[i]->counts};
     }
     a.blocks0 = n.blocks0 = blocks0;
-    a.clear[0] = reinterpret_cast<int32_t*>(scalars + kScalarResMax);
+    a.clear[0] = nullptr;
     a.clear[1] = ctx->stats;
+    a.clear_res = scratch_group_res(sc);
+    a.n_clear_res = sc.groups;
     a.dim = dim;
     a.K = n.K = K;
-    n.all_max = scalars + kScalarAllMax;
-    n.scale_out = scalars + kScalarScale2;
+    n.group_max = scratch_group_max(sc);
+    n.n_groups = sc.groups;
+    n.scale_out = scratch_scale(sc);
     hipLaunchKernelGGL(l2_pack_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, a);
     SFM_HIP_CHECK(ctx, hipGetLastError());
     if (mode == kL2F16) {
@@ -1436,7 +1471,7 @@ int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, L2Rows* rows0, cons
 int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int squared, const L2Rows& q,
                   const L2Rows& t, size_t frame_rows, int rows_cap, const int32_t* d_counts, int nq_uniform,
                   int nt_uniform, const int32_t* d_pairs, int n_problems, const L2Scratch& s,
-                  bool clear_todo) {
+                  int t_group0, bool clear_todo) {
     int32_t* todo_count = reinterpret_cast<int32_t*>(s.scalars + kScalarTodoCount);
     const int narrow_floats = mode == kL2F16 ? plan.K / 2 : plan.K;   // floats of a narrow row
     L2Args a{};
@@ -1444,7 +1479,7 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int sq
     a.t_base = mode == kL2F32 ? t.packed : t.narrow;
     a.t_norms = t.norms;
     a.t_acc0 = t.acc0;
-    a.narrow_scale = s.scalars + kScalarScale2;
+    a.narrow_scale = scratch_scale(s);
     a.frame_floats = frame_rows * (mode == kL2F32 ? plan.K : narrow_floats);
     a.rows_cap = rows_cap;
     a.counts = d_counts;
@@ -1486,9 +1521,9 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int sq
     r.cand_key = s.cand_key;
     r.cand_third = s.cand_third;
     r.q_norms = q.norms;
-    r.t_norm_max = s.scalars + kScalarAllMax;   // the queries' norms are in it too: a bound all the same
+    r.t_norm_max = scratch_group_max(s) + t_group0;   // indexed by the train frame
     r.q_res = mode == kL2F16 ? q.res : nullptr;
-    r.t_res_max = s.scalars + kScalarResMax;
+    r.t_res_max = scratch_group_res(s) + t_group0;
     // Per pass: roundings of the norms, of the accumulation steps (fp32: K, fp16: K exact
     // products, bfloat16: 3 K) and of the sequential sum, counted four per product.  bfloat16:
     // 4 * 2^-16 of the norms left out by the split.  Narrow passes: the position tag in a key's
@@ -1552,23 +1587,24 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
     Carver sz(nullptr);
     l2_rows_carve(sz, (size_t)(nq > 0 ? nq : 1), K, &q);
     l2_rows_carve(sz, (size_t)(nt > 0 ? nt : 1), K, &t);
-    l2_scratch_carve(sz, plan, rows_cap, 1, &sc);
+    l2_scratch_carve(sz, plan, rows_cap, 1, 2, &sc);
     void* ws;
     SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
     Carver c(ws);
     l2_rows_carve(c, (size_t)(nq > 0 ? nq : 1), K, &q);
     l2_rows_carve(c, (size_t)(nt > 0 ? nt : 1), K, &t);
-    l2_scratch_carve(c, plan, rows_cap, 1, &sc);
+    l2_scratch_carve(c, plan, rows_cap, 1, 2, &sc);
     // results go straight to the caller's arrays: one problem, so [q][2] is their layout
     sc.knn_idx = d_idx;
     sc.knn_dist = d_dist;
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(sc.scalars + kScalarTodoCount, 0, 2 * sizeof(float), ctx->stream));
+    SFM_RETURN_IF(l2_scratch_clear(ctx, sc));
     const L2Mode mode = l2_mode();
     SFM_RETURN_IF(l2_pack(ctx, mode, L2Source{d_q, nq, nq, 0, q_stride, nullptr}, &q,
                           L2Source{d_t, nt, nt, 0, t_stride, nullptr}, &t,
-                          false, dim, K, sc.scalars));
+                          false, dim, K, sc));
+    // (groups: the queries, then the train rows)
     SFM_RETURN_IF(l2_knn_packed(ctx, plan, mode, dim, squared, q, t, 0, rows_cap, nullptr, nq, nt, nullptr, 1, sc,
-                                false));
+                                nq > 0 ? 1 : 0, false));
     return SFM_OK;
 }
 
@@ -1583,7 +1619,7 @@ void l2_pairs_carve(Carver& c, const L2Plan& plan, int n_frames, int rows, int n
                     L2PairBuffers* b) {
     l2_rows_carve(c, (size_t)n_frames * rows, plan.K, &b->rows);
     const size_t nprob = 2 * (size_t)n_pairs;
-    l2_scratch_carve(c, plan, rows, nprob, &b->sc);
+    l2_scratch_carve(c, plan, rows, nprob, n_frames, &b->sc);
     b->best = c.take<int32_t>(nprob * rows);
     b->best_dist = c.take<float>(nprob * rows);
 }
@@ -1620,20 +1656,20 @@ int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_fr
     SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
     Carver c(ws);
     l2_pairs_carve(c, plan, n_frames, rows_per_frame, chunk, &b);
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(b.sc.scalars + kScalarTodoCount, 0, 2 * sizeof(float), ctx->stream));
+    SFM_RETURN_IF(l2_scratch_clear(ctx, b.sc));
     const L2Mode mode = l2_mode();
     // every frame in one launch, each serving as query and as train set; rows beyond a frame's
     // count are packed too (they are never read)
     L2Rows spare = b.rows;
     SFM_RETURN_IF(l2_pack(ctx, mode, L2Source{d_desc, n_frames * rows_per_frame, rows_per_frame, frame_stride,
                                               (size_t)dim * 4, d_counts},
-                          &b.rows, L2Source{nullptr, 0, 1, 0, 0, nullptr}, &spare, true, dim, plan.K, b.sc.scalars));
+                          &b.rows, L2Source{nullptr, 0, 1, 0, 0, nullptr}, &spare, true, dim, plan.K, b.sc));
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
         const int np = chunk < n_pairs - p0 ? chunk : n_pairs - p0;
         const int32_t* pairs = d_pairs + 2 * (size_t)p0;
         SFM_RETURN_IF(l2_knn_packed(ctx, plan, mode, dim, squared, b.rows, b.rows, (size_t)rows_per_frame,
                                     rows_per_frame, d_counts, rows_per_frame, rows_per_frame, pairs, 2 * np,
-                                    b.sc, true));
+                                    b.sc, 0, true));
         SFM_RETURN_IF(launch_ratio_cross_knn(ctx, b.sc.knn_idx, b.sc.knn_dist, rows_per_frame, d_counts,
                                              rows_per_frame, pairs, np, ratio, b.best, b.best_dist,
                                              d_matches + (size_t)p0 * cap, cap,
