@@ -1347,10 +1347,10 @@ struct L2Scratch {
     float* knn_dist;
 };
 constexpr int kExhaustiveGrid = 1024;
-// scalars: [spare][count of listed queries][spare][largest norm per group ...]
-// [largest residual per group ...][s^2][1 / s^2].  The count and the groups' largest norms are
-// cleared before the rows are packed (one memset).
-enum { kScalarSpare = 0, kScalarTodoCount, kScalarUnused, kScalarGroups };
+// scalars: [count of listed queries][spare][largest norm per group ...][largest residual per
+// group ...][s^2][1 / s^2].  The count and the groups' largest norms are cleared before the rows
+// are packed: one memset from the (256-byte aligned) start of the array.
+enum { kScalarTodoCount = 0, kScalarUnused, kScalarGroups };
 inline float* scratch_group_max(const L2Scratch& s) { return s.scalars + kScalarGroups; }
 inline float* scratch_group_res(const L2Scratch& s) { return s.scalars + kScalarGroups + s.groups; }
 inline float* scratch_scale(const L2Scratch& s) { return s.scalars + kScalarGroups + 2 * s.groups; }
@@ -1367,7 +1367,7 @@ void l2_scratch_carve(Carver& c, const L2Plan& plan, int rows_cap, size_t n_prob
     s->knn_dist = c.take<float>(n_problems * rows_cap * 2);
 }
 int l2_scratch_clear(sfm_ctx* ctx, const L2Scratch& s) {
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(s.scalars + kScalarTodoCount, 0, (2 + (size_t)s.groups) * sizeof(float),
+    SFM_HIP_CHECK(ctx, hipMemsetAsync(s.scalars, 0, (kScalarGroups + (size_t)s.groups) * sizeof(float),
                                       ctx->stream));
     return SFM_OK;
 }
