@@ -167,20 +167,26 @@ def max_over_ranks(seconds, world, dev):
     return float(t.item())
 
 
-def timed_steps(step, steps, warmup, world, dev, ctx, more_ctx=()):
+def timed_steps(step, steps, warmup, world, dev, ctx, more_ctx=(), profile_step=None, profile_ctxs=None):
     """W untimed steps, then K timed ones between barrier + device-wide synchronize (all
-    streams).  Per-kernel HIP-event times of every context involved are merged."""
-    ctxs = (ctx,) + tuple(more_ctx)
+    streams), with the library's per-kernel timing off: its HIP events around every launch
+    would sit in the timed streams.  The per-kernel times come from a second pass of K steps
+    after the timed region (`profile_step`, default the same step) with the events on."""
     for _ in range(warmup):
         step()
-    for c in ctxs:
-        c.set_profiling(True)
     barrier_sync(world)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     barrier_sync(world)
     dt = time.perf_counter() - t0
+    ctxs = tuple(profile_ctxs) if profile_ctxs is not None else (ctx,) + tuple(more_ctx)
+    for c in ctxs:
+        c.set_profiling(True)
+    pstep = profile_step or step
+    for _ in range(steps):
+        pstep()
+    barrier_sync(world)
     prof = {}
     for c in ctxs:
         prof.update(c.profile())
@@ -364,8 +370,10 @@ def run_framepair(args, rank, world, local):
         return step
 
     step = make_step(ctx_lk)
+    # kernel durations without the overlap: the same step on one stream, after the timed
+    # region (not part of `value`)
     dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, ctx,
-                           () if ctx_lk is ctx else (ctx_lk,))
+                           profile_step=make_step(ctx), profile_ctxs=(ctx,))
     feats_step = world * P * (2 * KPS + LK_POINTS)
     value = feats_step * args.steps / dt
     # the same step looped for at least --sustain seconds: a rate at the clock the chip holds
@@ -388,10 +396,6 @@ def run_framepair(args, rank, world, local):
         dt_sus = max_over_ranks(time.perf_counter() - t0, world, dev)
         sustained = {"value": round(feats_step * n_sus / dt_sus, 1), "unit": "features/s", "steps": n_sus,
                      "seconds": round(dt_sus, 3), "ms_per_step": round(1e3 * dt_sus / n_sus, 4)}
-    if two_streams:
-        # kernel durations without the overlap: the same step on one stream, after the timed
-        # region (not part of `value`)
-        _, prof = timed_steps(make_step(ctx), args.steps, 1, world, dev, ctx)
     matched = int(d_mcount.sum().item())
     if gather is not None:
         gathered["n"] = int(gather.counts.sum().item())
