@@ -91,6 +91,17 @@ __device__ __forceinline__ void top2_pair(uint32_t& m1, uint32_t& m2, uint32_t x
     asm("v_min3_u32 %0, %0, %1, %2" : "+v"(m1) : "v"(x), "v"(y));
 }
 
+// Four keys at once in five instructions: two of the steps above with the two updates of m2
+// joined into one v_min3.
+__device__ __forceinline__ void top2_quad(uint32_t& m1, uint32_t& m2, uint32_t x0, uint32_t y0, uint32_t x1,
+                                          uint32_t y1) {
+    const uint32_t a = med3_u32(m1, x0, y0);
+    asm("v_min3_u32 %0, %0, %1, %2" : "+v"(m1) : "v"(x0), "v"(y0));
+    const uint32_t b = med3_u32(m1, x1, y1);
+    asm("v_min3_u32 %0, %0, %1, %2" : "+v"(m2) : "v"(a), "v"(b));
+    asm("v_min3_u32 %0, %0, %1, %2" : "+v"(m1) : "v"(x1), "v"(y1));
+}
+
 // One thread per descriptor word: 32 bits become 32 four-bit floats (16 bytes), bit 0 -> +1
 // (0x2), bit 1 -> -1 (0xA); nibble b of a row is bit b of the descriptor.
 __global__ __launch_bounds__(256) void hamming_expand_kernel(const uint32_t* __restrict__ packed,
@@ -217,21 +228,26 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
 
     // Two accumulator sets, one per half of a tile.  While the matrix pipe accumulates one half
     // tile into one set, the vector ALU folds the other set (the previous half tile) into the
-    // best-two lists, a slice of it after every k step, so the fold hides behind the MFMAs.
-    constexpr int kGroups = 4;  // slices of a set: 4 accumulator registers of every query tile
+    // best-two lists: behind every MFMA the same share of it, so that the wave offers the
+    // issue port one MFMA and about five vector instructions in turn.
     floatx16 acc0[NT], acc1[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[n][r] = acc1[n][r] = kMasked;
 
-    auto fold_group = [&](const floatx16 (&acc)[NT], int gq) {
+    // Pairs [p0, p1) of the eight register pairs of query tile n's accumulator; consecutive
+    // pairs go to the same one of the tile's two lists (four keys in five instructions).
+    auto fold_pairs = [&](const floatx16 (&acc)[NT], int n, int p0, int p1) {
+        int p = p0;
 #pragma unroll
-        for (int r = 0; r < 4; r += 2)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-                top2_pair(m1[n][r >> 1], m2[n][r >> 1], __float_as_uint(acc[n][4 * gq + r]),
-                          __float_as_uint(acc[n][4 * gq + r + 1]));
+        for (; p + 1 < p1; p += 2)
+            top2_quad(m1[n][(p >> 1) & 1], m2[n][(p >> 1) & 1], __float_as_uint(acc[n][2 * p]),
+                      __float_as_uint(acc[n][2 * p + 1]), __float_as_uint(acc[n][2 * p + 2]),
+                      __float_as_uint(acc[n][2 * p + 3]));
+        if (p < p1)
+            top2_pair(m1[n][(p >> 1) & 1], m2[n][(p >> 1) & 1], __float_as_uint(acc[n][2 * p]),
+                      __float_as_uint(acc[n][2 * p + 1]));
     };
 
     const int left = t_end - t_begin;
@@ -289,17 +305,12 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
                 // cbsz = blgp = 4: both operands E2M1; block scales 2^6 x 2^6
                 accC[n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
                     a8, b8, m == 0 ? start : accC[n], 4, 4, 0, scale, 0, scale);
+                // This tile's share of the other set, whose last MFMA was issued NT MFMAs ago.
+                // The barrier keeps the share behind its MFMA (the compiler otherwise gathers
+                // the fold in front of the MFMAs).
+                fold_pairs(accF, n, (8 * m) / KS, (8 * (m + 1)) / KS);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // The fold of the other set starts one k step late (that set's last MFMAs were
-            // issued just before this half tile) and is spread over the remaining k steps.
-            if (m > 0) {
-#pragma unroll
-                for (int gi = ((m - 1) * kGroups) / (KS - 1); gi < (m * kGroups) / (KS - 1); ++gi)
-                    fold_group(accF, gi);
-            }
-            // keep every k step's MFMAs and its share of the fold together: the compiler
-            // otherwise gathers the whole fold in front of the MFMAs
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
     }
     if (ntiles > 0) tile_body(lds + ((ntiles - 1) & 1) * kTileBytes, (ntiles - 1) * kTileRows, true);
 #pragma unroll
-    for (int gi = 0; gi < kGroups; ++gi) fold_group(acc1, gi);
+    for (int n = 0; n < NT; ++n) fold_pairs(acc1, n, 0, 8);
 
     // accumulator -> (distance << 18 | train index); the two lane halves saw different rows
     auto to_key = [&](uint32_t bits) {

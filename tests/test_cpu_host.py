@@ -272,3 +272,13 @@ def test_adapter_opencv_branch_compiles():
                         "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adapter_check.cpp")],
                        capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-4000:]
+
+
+def test_hamming_fold_stays_behind_its_mfma():
+    """The Hamming kernel's fold reads MFMA results through inline asm, where the compiler adds
+    no wait states of its own: in the emitted ISA every such read must lie at least the 11
+    wait states of an 8-pass MFMA behind the instruction that wrote the register."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazards.py"), "--min", "11"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("hamming_mfma_kernel") >= 4, out.stdout
