@@ -9,13 +9,15 @@
 // s(0) = +1 and s(1) = -1, a train row as s(t) and a query row as -s(q),
 //     sum_k s(t_k) * (-s(q_k)) = #differing - #equal = 2 h - B.
 // The units are 4-bit floats (E2M1: +1 = 0x2, -1 = 0xA), the densest operand the matrix pipe
-// takes: v_mfma_scale_f32_32x32x64_f8f6f4 contracts 64 bits per instruction and multiplies
-// each operand by a power-of-two block scale, here 2^6 for both, so one differing bit adds
-// 8192 and the sum is exact in the float accumulator (|sum| <= 4096 B < 2^24).  The
-// accumulator of train row r starts at 4096 B + (r - first row of the workgroup's train
-// range), so when the k loop ends it IS the ranking key  8192 h + local train index  (a
-// workgroup's range holds at most 8192 rows): no instruction builds keys, and positive floats
-// order like their bit patterns, so the lists are kept with integer min / median
+// takes: v_mfma_f32_32x32x64_f8f6f4 contracts 64 bits per instruction, and the sum is a small
+// integer, exact in the float accumulator.  (The block-scaled form of the instruction, which
+// an earlier version used to make one differing bit worth 8192, occupies the issue port
+// longer: 721 against 695 us on the default launch.)  The accumulator of train row r starts
+// at  B + (r - first row of the workgroup's train range) / 8192,  so when the k loop ends it
+// IS the ranking key  2 h + local train index / 8192  (a workgroup's range holds at most 8192
+// rows; 2 h <= 1024 for rows of up to 64 bytes, which leaves the float its 13 fraction bits):
+// no instruction builds keys, and positive
+// floats order like their bit patterns, so the lists are kept with integer min / median
 // instructions.  Train tiles are the A operand (rows), the queries the B operand (columns):
 // each lane's 16 accumulator registers are 16 train rows of ONE query, so the running
 // best-two of that query stay in the lane's registers and take three instructions per two
@@ -48,7 +50,6 @@ constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 constexpr uint32_t kEmpty = 0x7F7FFFFFu;   // tracker start (FLT_MAX), above every accumulator
 constexpr float kMasked = 1e30f;           // accumulator start of a row past the range
 constexpr float kRealLimit = 1e20f;
-constexpr int kScale = 127 + 6;            // E8M0 block scale 2^6 of both operands
 constexpr int kAhead = 2;                  // fragment reads run this many k steps ahead
 
 struct MfmaArgs {
@@ -218,12 +219,13 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
     if (ntiles > 0) stage(0, 0);
 
     // accumulator start: register r of a 32-row half tile is its train row 8(r>>2) + 4lh + (r&3);
-    // it starts at 4096 * bits + the row's index in the workgroup's range.  The start values of
+    // it starts at the number of bits + the row's index in the workgroup's range / 8192.  The start values of
     // a half tile are formed afresh (a per-lane value + one constant per register): a vector
     // updated in place would be live across the MFMAs that start from it and cost a register
     // copy per half tile.
-    const float lane_base = (float)(4096 * 32 * W + 4 * lh);
-    const int scale = kScale;
+    constexpr float kUnit = 1.f / (float)(1 << kLocalBits);   // one index step in the key
+    const float lane_base = (float)(32 * W) + (float)(4 * lh) * kUnit;
+    const int scale = 0;
     __syncthreads();
 
     // Two accumulator sets, one per half of a tile.  While the matrix pipe accumulates one half
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
         intx4 ring[kRing];
 #pragma unroll
         for (int s = 0; s < kAhead && s < kSteps; ++s) ring[s] = frag(s);
-        const float first_base = lane_base + (float)first;
+        const float first_base = lane_base + (float)first * kUnit;
 #pragma clang loop unroll(full)
         for (int s = 0; s < kSteps; ++s) {
             const int mt = s / KS, m = s % KS;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
                 for (int r = 0; r < 16; ++r)
                     asm("v_add_f32 %0, %1, %2"
                         : "=v"(start[r])
-                        : "s"((float)(32 * mt + 8 * (r >> 2) + (r & 3))), "v"(first_base));
+                        : "s"((float)(32 * mt + 8 * (r >> 2) + (r & 3)) * kUnit), "v"(first_base));
                 if (masked) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -302,7 +304,8 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
             for (int n = 0; n < NT; ++n) {
                 const intx4 bv = breg[n][m];
                 const intx8 b8 = {bv[0], bv[1], bv[2], bv[3], 0, 0, 0, 0};
-                // cbsz = blgp = 4: both operands E2M1; block scales 2^6 x 2^6
+                // cbsz = blgp = 4: both operands E2M1; scale operands 0, 0 select the unscaled
+                // instruction
                 accC[n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
                     a8, b8, m == 0 ? start : accC[n], 4, 4, 0, scale, 0, scale);
                 // This tile's share of the other set, whose last MFMA was issued NT MFMAs ago.
@@ -327,8 +330,8 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
     // accumulator -> (distance << 18 | train index); the two lane halves saw different rows
     auto to_key = [&](uint32_t bits) {
         const float f = __uint_as_float(bits);
-        const uint32_t v = (uint32_t)f;
-        const uint32_t h = v >> kLocalBits, local = v & ((1u << kLocalBits) - 1);
+        const uint32_t v = (uint32_t)(f * (float)(1 << kLocalBits));   // 2 h << 13 | local, exact
+        const uint32_t h = v >> (kLocalBits + 1), local = v & ((1u << kLocalBits) - 1);
         return f < kRealLimit ? (h << kIdxBits) | (uint32_t)(t_begin + (int)local) : kNoKey;
     };
     uint2* out = a.keys + ((size_t)problem * a.splits + split) * (size_t)a.rows_max;
