@@ -17,8 +17,8 @@
 // IS the ranking key  2 h + local train index / 8192  (a workgroup's range holds at most 8192
 // rows; 2 h <= 1024 for rows of up to 64 bytes, which leaves the float its 13 fraction bits):
 // no instruction builds keys, and positive
-// floats order like their bit patterns, so the lists are kept with integer min / median
-// instructions.  Train tiles are the A operand (rows), the queries the B operand (columns):
+// floats order like their bit patterns, so the lists are kept with float min / median
+// instructions in the main loop and with integer ones on the final keys.  Train tiles are the A operand (rows), the queries the B operand (columns):
 // each lane's 16 accumulator registers are 16 train rows of ONE query, so the running
 // best-two of that query stay in the lane's registers and take three instructions per two
 // distances (top2_pair).  The minimum of (distance, index) keys does not depend on the
@@ -85,22 +85,29 @@ __device__ __forceinline__ void top2(uint32_t& m1, uint32_t& m2, uint32_t key) {
     m1 = min(m1, key);
 }
 
+// The lists of the main loop are kept on the keys as floats (non-negative, so they order like
+// their bit patterns): v_med3_f32 / v_min3_f32 through the compiler, which then knows the
+// readers of an MFMA result and what follows them (asm statements cost a wait state each
+// here: the compiler takes an asm result for that of a transcendental instruction).
+__device__ __forceinline__ float fmin3(float a, float b, float c) {
+    return __builtin_fminf(__builtin_fminf(a, b), c);
+}
+
 // Two keys at once in three instructions (v_med3, v_min, v_min3) instead of four: with
 // m1 <= m2, the second smallest of {m1, m2, x, y} is min(m2, median(m1, x, y)).
-__device__ __forceinline__ void top2_pair(uint32_t& m1, uint32_t& m2, uint32_t x, uint32_t y) {
-    m2 = min(m2, med3_u32(m1, x, y));
-    asm("v_min3_u32 %0, %0, %1, %2" : "+v"(m1) : "v"(x), "v"(y));
+__device__ __forceinline__ void top2_pair(float& m1, float& m2, float x, float y) {
+    m2 = __builtin_fminf(m2, __builtin_amdgcn_fmed3f(m1, x, y));
+    m1 = fmin3(m1, x, y);
 }
 
 // Four keys at once in five instructions: two of the steps above with the two updates of m2
 // joined into one v_min3.
-__device__ __forceinline__ void top2_quad(uint32_t& m1, uint32_t& m2, uint32_t x0, uint32_t y0, uint32_t x1,
-                                          uint32_t y1) {
-    const uint32_t a = med3_u32(m1, x0, y0);
-    asm("v_min3_u32 %0, %0, %1, %2" : "+v"(m1) : "v"(x0), "v"(y0));
-    const uint32_t b = med3_u32(m1, x1, y1);
-    asm("v_min3_u32 %0, %0, %1, %2" : "+v"(m2) : "v"(a), "v"(b));
-    asm("v_min3_u32 %0, %0, %1, %2" : "+v"(m1) : "v"(x1), "v"(y1));
+__device__ __forceinline__ void top2_quad(float& m1, float& m2, float x0, float y0, float x1, float y1) {
+    const float a = __builtin_amdgcn_fmed3f(m1, x0, y0);
+    m1 = fmin3(m1, x0, y0);
+    const float b = __builtin_amdgcn_fmed3f(m1, x1, y1);
+    m2 = fmin3(m2, a, b);
+    m1 = fmin3(m1, x1, y1);
 }
 
 // One thread per descriptor word: 32 bits become 32 four-bit floats (16 bytes), bit 0 -> +1
@@ -188,9 +195,9 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
     }
     // best two per query tile, kept twice (even and odd accumulator pairs) so that the
     // vector ALU always has independent chains to issue from; merged at the end
-    uint32_t m1[NT][2], m2[NT][2];
+    float m1[NT][2], m2[NT][2];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) m1[n][0] = m1[n][1] = m2[n][0] = m2[n][1] = kEmpty;
+    for (int n = 0; n < NT; ++n) m1[n][0] = m1[n][1] = m2[n][0] = m2[n][1] = __uint_as_float(kEmpty);
 
     // this workgroup's train range: whole tiles, at most 2^kLocalBits rows
     const int units_total = (nt + kTileUnit - 1) / kTileUnit;
@@ -244,12 +251,10 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
         int p = p0;
 #pragma unroll
         for (; p + 1 < p1; p += 2)
-            top2_quad(m1[n][(p >> 1) & 1], m2[n][(p >> 1) & 1], __float_as_uint(acc[n][2 * p]),
-                      __float_as_uint(acc[n][2 * p + 1]), __float_as_uint(acc[n][2 * p + 2]),
-                      __float_as_uint(acc[n][2 * p + 3]));
+            top2_quad(m1[n][(p >> 1) & 1], m2[n][(p >> 1) & 1], acc[n][2 * p], acc[n][2 * p + 1],
+                      acc[n][2 * p + 2], acc[n][2 * p + 3]);
         if (p < p1)
-            top2_pair(m1[n][(p >> 1) & 1], m2[n][(p >> 1) & 1], __float_as_uint(acc[n][2 * p]),
-                      __float_as_uint(acc[n][2 * p + 1]));
+            top2_pair(m1[n][(p >> 1) & 1], m2[n][(p >> 1) & 1], acc[n][2 * p], acc[n][2 * p + 1]);
     };
 
     const int left = t_end - t_begin;
@@ -328,8 +333,7 @@ __global__ __launch_bounds__(kThreads) void hamming_mfma_kernel(MfmaArgs a) {
     for (int n = 0; n < NT; ++n) fold_pairs(acc1, n, 0, 8);
 
     // accumulator -> (distance << 18 | train index); the two lane halves saw different rows
-    auto to_key = [&](uint32_t bits) {
-        const float f = __uint_as_float(bits);
+    auto to_key = [&](float f) {
         const uint32_t v = (uint32_t)(f * (float)(1 << kLocalBits));   // 2 h << 13 | local, exact
         const uint32_t h = v >> (kLocalBits + 1), local = v & ((1u << kLocalBits) - 1);
         return f < kRealLimit ? (h << kIdxBits) | (uint32_t)(t_begin + (int)local) : kNoKey;

@@ -23,7 +23,7 @@ SRC = os.path.join(ROOT, "sfm_amd", "csrc", "hamming_mfma.hip")
 
 def compile_to_asm(path):
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
-           "-fno-fast-math", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(SRC), "-S",
+           "-fno-fast-math", "-fno-honor-nans", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(SRC), "-S",
            "--cuda-device-only", SRC, "-o", path]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
