@@ -275,9 +275,9 @@ def test_adapter_opencv_branch_compiles():
 
 
 def test_hamming_fold_stays_behind_its_mfma():
-    """The Hamming kernel's fold reads MFMA results through inline asm, where the compiler adds
-    no wait states of its own: in the emitted ISA every such read must lie at least the 11
-    wait states of an 8-pass MFMA behind the instruction that wrote the register."""
+    """gfx950 does not interlock a vector read of an MFMA result, and the compiler adds no wait
+    states for a reader inside an asm statement: in the emitted ISA of the Hamming kernel every
+    such read must lie at least the 11 wait states of an 8-pass MFMA behind its writer."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazards.py"), "--min", "11"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr

@@ -1,12 +1,14 @@
 """Static check of the Hamming matrix-core kernel's ISA: how many wait states lie between an
 MFMA and the first vector instruction that reads its result.
 
-The fold of hamming_mfma.hip reads accumulators through inline asm (v_med3_u32 / v_min3_u32),
-and the compiler inserts the wait states gfx950 needs between an MFMA and a reader of its
-result only for instructions it selected itself.  The kernel keeps every reader several MFMAs
-behind the writer; this script compiles the file to assembly and measures that distance in the
-code the compiler actually emitted: one wait state per instruction, N + 1 per `s_nop N`, eight
-per MFMA in between (an 8-pass MFMA holds the pipe that long).  An 8-pass MFMA needs 11.
+gfx950 does not interlock that read: the compiler inserts the wait states an instruction it
+selected itself needs, but none for a reader inside an asm statement, and it may move such a
+statement up to right behind the MFMA.  hamming_mfma.hip keeps the fold of an accumulator
+several MFMAs behind its last writer; this script compiles the file to assembly and measures
+the distance in the code the compiler actually emitted: one wait state per instruction, N + 1
+per `s_nop N`, eight per MFMA in between (an 8-pass MFMA holds the pipe that long).  An 8-pass
+MFMA needs 11.  The fold is written with compiler-visible instructions today; the check stays
+as a guard for the next rewrite.
 
     python3 tools/check_mfma_hazards.py [--min 11]
 """
