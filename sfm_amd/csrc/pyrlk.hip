@@ -585,9 +585,16 @@ __device__ __forceinline__ void window_interp(const uint8_t* base, unsigned o, i
 
 // LPP = lanes per point: 64 (one point per wave) or 16 (four points per wave, one per
 // DPP row; the per-point scalar work is then shared by four points per instruction).
-template <int LPP, int SPL, bool FULL>
+// VERT (21 x 21 windows on 16 lanes): a lane's four slots are the same seven columns of four
+// consecutive window rows (lanes 0..14: rows 4 (lane / 3) .. + 3 of segment lane % 3), so the
+// lower image row of one slot is the upper row of the next and five row loads serve four
+// slots instead of eight; lane 15 takes the three slots of window row 20 and loads their
+// upper rows by itself.
+template <int LPP, int SPL, bool FULL, bool VERT = false>
 __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
+    static_assert(!VERT || (LPP == 16 && SPL == 4 && FULL), "vertical groups: 21 x 21 windows on 16 lanes");
     const int lane = threadIdx.x & (LPP - 1);
+    const bool own_rows = VERT && lane == 15;   // the lane whose slots sit side by side
     // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); give each XCD one
     // contiguous eighth of the points, so that an image pair's pyramids are fetched into
     // one L2 instead of all eight.
@@ -614,6 +621,14 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
     SlotMask<FULL> msk[SPL];
 #pragma unroll
     for (int s = 0; s < SPL; ++s) {
+        if (VERT) {
+            // lane 15's fourth slot does not exist: it repeats the third one's place (loads stay
+            // inside the level) and counts as invalid below
+            const int srow = own_rows ? 20 : 4 * (lane / 3) + s;
+            const int sx0 = (own_rows ? min(s, 2) : lane % 3) * kPxPerSlot;
+            sgeom[s] = (srow << 8) | sx0;
+            continue;
+        }
         const int slot = lane + LPP * s;
         const bool valid = slot < a.slots;
         const int sl = valid ? slot : 0;
@@ -621,6 +636,34 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
         sgeom[s] = (srow << 8) | sx0;
         msk[s].set(valid ? min(kPxPerSlot, a.win_w - sx0) : 0);
     }
+    auto slot_valid = [&](int s) { return VERT ? !(own_rows && s == 3) : lane + LPP * s < a.slots; };
+    // The rows of all slots of a lane from one image: up[s] / lo[s] are the upper and lower row
+    // of slot s.  VERT: five loads by every lane (the first slot's upper row and every slot's
+    // lower row) and two more by lane 15 alone.
+    auto load_rows8 = [&](const uint8_t* base, unsigned o0, const unsigned (&soff)[SPL], int S, uint2 (&up)[SPL],
+                          uint2 (&lo)[SPL]) {
+        if (!VERT) {
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                up[s] = load_u8x8(base + (o0 + soff[s]));
+                lo[s] = load_u8x8(base + (o0 + soff[s] + (unsigned)S));
+            }
+            return;
+        }
+        // lane 15's own loads first, into registers of their own: all seven loads are then in
+        // flight together (a load that overwrote a copy of lo[] would have to wait for it)
+        uint2 x1 = make_uint2(0, 0), x2 = x1;
+        if (own_rows) {
+            x1 = load_u8x8(base + (o0 + soff[1]));
+            x2 = load_u8x8(base + (o0 + soff[2]));
+        }
+        up[0] = load_u8x8(base + (o0 + soff[0]));
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) lo[s] = load_u8x8(base + (o0 + soff[s] + (unsigned)S));
+        up[1] = own_rows ? x1 : lo[0];
+        up[2] = own_rows ? x2 : lo[1];
+        up[3] = lo[2];
+    };
 
     const float2 p0 = a.prev_pts[pt];
     const float half_x = (a.win_w - 1) * 0.5f, half_y = (a.win_h - 1) * 0.5f;
@@ -667,16 +710,44 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
 
         int pA[3] = {0, 0, 0};
         const unsigned obase = (unsigned)((ipy + g.bh) * S + ipx + g.bw);
+        uint2 iu[SPL], il[SPL];
+        uint4 du[SPL][2], dl[SPL][2];   // VERT: the derivative rows of the lane's slots, loaded once
+        if (VERT) {
+            load_rows8(I, obase, soff, S, iu, il);
+            auto load_d = [&](unsigned o, uint4 (&r)[2]) { __builtin_memcpy(r, D + o, 32); };
+            // an invalid slot reads the zero border at the start of the padded level
+            uint4 dx1[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)}, dx2[2] = {dx1[0], dx1[0]};
+            if (own_rows) {
+                load_d(obase + soff[1], dx1);
+                load_d(obase + soff[2], dx2);
+            }
+            load_d(obase + soff[0], du[0]);
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) load_d(slot_valid(s) ? obase + soff[s] + (unsigned)S : 0u, dl[s]);
+            auto pick = [&](const uint4& mine, const uint4& shared) {
+                return make_uint4(own_rows ? mine.x : shared.x, own_rows ? mine.y : shared.y,
+                                  own_rows ? mine.z : shared.z, own_rows ? mine.w : shared.w);
+            };
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                du[1][h] = pick(dx1[h], dl[0][h]);
+                du[2][h] = pick(dx2[h], dl[1][h]);
+                du[3][h] = pick(make_uint4(0, 0, 0, 0), dl[2][h]);   // lane 15's fourth slot: zero derivatives
+            }
+        }
 #pragma unroll
         for (int s = 0; s < SPL; ++s) {
             SlotWin& w = win[s];
-            const bool valid = lane + LPP * s < a.slots;
+            const bool valid = slot_valid(s);
             const uint32_t m01 = msk[s].p01(valid), m23 = msk[s].p23(valid), m45 = msk[s].p45(valid);
             const int m6 = msk[s].p6(valid);
             const unsigned o = obase + soff[s];
             uint32_t i01, i23, i45;
             int i6;
-            window_interp(I, o, S, wt, i01, i23, i45, i6);
+            if (VERT)
+                window_interp(iu[s], il[s], wt, i01, i23, i45, i6);
+            else
+                window_interp(I, o, S, wt, i01, i23, i45, i6);
             if (FULL) {  // a slot outside the window contributes through its zero derivatives only
                 w.i01 = i01;
                 w.i23 = i23;
@@ -692,8 +763,13 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
             // (at least 3 rows and 16 columns) instead of being masked afterwards
             const unsigned od = FULL ? (valid ? o : 0u) : o;
             uint32_t d0[8], d1[8];
-            __builtin_memcpy(d0, D + od, 32);
-            __builtin_memcpy(d1, D + (od + (unsigned)S), 32);
+            if (VERT) {
+                __builtin_memcpy(d0, du[s], 32);
+                __builtin_memcpy(d1, dl[s], 32);
+            } else {
+                __builtin_memcpy(d0, D + od, 32);
+                __builtin_memcpy(d1, D + (od + (unsigned)S), 32);
+            }
             // column pairs (row y, row y+1) of Ix and of Iy, then CV_DESCALE(..., W_BITS)
             uint32_t xp[8], yp[8];
 #pragma unroll
@@ -776,12 +852,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
             int pb[2] = {0, 0};
             const unsigned jbase = (unsigned)((iny + g.bh) * S + inx + g.bw);
             if (inx != held_x || iny != held_y) {
-#pragma unroll
-                for (int s = 0; s < SPL; ++s) {
-                    const unsigned o = jbase + soff[s];
-                    ja[s] = load_u8x8(J + o);
-                    jb[s] = load_u8x8(J + (o + (unsigned)S));
-                }
+                load_rows8(J, jbase, soff, S, ja, jb);
                 held_x = inx;
                 held_y = iny;
             }
@@ -838,7 +909,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) {
                     const SlotWin& w = win[s];
-                    const bool valid = lane + LPP * s < a.slots;
+                    const bool valid = slot_valid(s);
                     const uint32_t m01 = msk[s].p01(valid), m23 = msk[s].p23(valid), m45 = msk[s].p45(valid);
                     const int m6 = msk[s].p6(valid);
                     const unsigned o = ebase + soff[s];
@@ -1131,6 +1202,10 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         else                                                                                          \
             hipLaunchKernelGGL((lk_track_kernel<LPP_, SPL_, false>), grid, blk, 0, ctx->stream, a);   \
     } while (0)
+        static const bool no_vert = getenv("SFM_LK_NO_VERT") != nullptr;   // measurement aid
+        if (a.win_w == 21 && a.win_h == 21 && !no_vert) {
+            hipLaunchKernelGGL((lk_track_kernel<16, 4, true, true>), grid, blk, 0, ctx->stream, a);
+        } else
         switch ((a.slots + 15) / 16) {
             case 1: SFM_LK_LAUNCH(16, 1); break;
             case 2: SFM_LK_LAUNCH(16, 2); break;

@@ -14,6 +14,7 @@ from sfm_amd import capi, synth  # noqa: E402
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+    fixed_win = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # e.g. 21: every case with a 21 x 21 window
     rng = np.random.default_rng(4242)
     ctx = capi.Context(0)
     bad = 0
@@ -25,6 +26,8 @@ def main():
             prev[: h // 3, : w // 2] = 90
             curr[: h // 3, : w // 2] = 90
         win = (int(rng.integers(3, 34)), int(rng.integers(3, 34)))
+        if fixed_win:
+            win = (fixed_win, fixed_win)
         max_level = int(rng.integers(0, 5))
         crit = int(rng.choice([1, 2, 3]))
         max_count = int(rng.choice([1, 5, 30, 100]))
