@@ -225,7 +225,7 @@ def lk_roofline(prof, n_pairs, iters_per_point):
             "iterations_source": "cpu_baseline leg of this run" if iters_per_point else "constant",
             "compulsory_hbm_bytes": compulsory,
             "compulsory_hbm_GBps": round(compulsory / sec / 1e9, 1),
-            "second_limit": "the CU's vector memory path: the window gathers keep it busy 73 % of the "
+            "second_limit": "the CU's vector memory path: the window gathers keep it busy 62 % of the "
                             "kernel's cycles (TA_TA_BUSY, tools/pmc_ta.sh) beside the vector ALU",
             "traffic": None}
 
