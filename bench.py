@@ -123,6 +123,12 @@ def dist_setup(n_gpus, force_group=False):
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # SFM_BENCH_REHEARSE=1: the multi-rank code on fewer GPUs than ranks (ranks share the
+        # cards round-robin and the collectives go through gloo; RCCL refuses two ranks on one
+        # device).  It checks the N > 1 control flow on a one-GPU box; its timings mean nothing.
+        rehearse = os.environ.get("SFM_BENCH_REHEARSE", "0") == "1"
+        if rehearse:
+            local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
         # RCCL prints a version banner on stdout when its communicator comes up; stdout is for
         # the one JSON line, so the banner goes to stderr
@@ -130,7 +136,10 @@ def dist_setup(n_gpus, force_group=False):
         keep = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            if rehearse:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
             warm = torch.zeros(1, device=torch.device("cuda", local))
             dist.all_reduce(warm)
             torch.cuda.synchronize()
@@ -1120,6 +1129,10 @@ def main():
         sys.exit(spawn_ranks(args))
     if args.workload == "ranks":
         return run_ranks()
+    if os.environ.get("SFM_BENCH_WATCHDOG"):   # seconds: a hung rank prints its stacks and exits
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["SFM_BENCH_WATCHDOG"]), exit=True)
     rank, world, local = dist_setup(args.gpus, args.force_gather)
     run = {"framepair": run_framepair, "c3": run_c3, "c4": run_c4, "c5": run_c5, "f1": run_f1, "f2": run_f2, "f3": run_f3, "vo": run_vo}[args.workload]
     out = run(args, rank, world, local)
