@@ -208,9 +208,11 @@ __device__ __forceinline__ void null_vector_jacobi(double (&At)[4][4], double (&
 constexpr int kMaxInvIt = 10;
 
 // Solves (M - shift I) x = b by L D L^T; M symmetric, given by its upper triangle
-// m[] = {00,01,02,03,11,12,13,22,23,33}.  Returns false when one of the first three
-// pivots is not positive (the shift was not below the spectrum); a non-positive last
-// pivot is replaced by a tiny positive one (exactly singular system).
+// m[] = {00,01,02,03,11,12,13,22,23,33}.  Returns false when the shift was not below the
+// spectrum: one of the first three pivots not positive, or the last one negative by more
+// than rounding (1e17 tiny = 1e-13 trace; a matrix with one negative eigenvalue can have its
+// one negative pivot in the last place).  A last pivot within rounding of zero is replaced
+// by a tiny positive one (exactly singular system).
 __device__ __forceinline__ bool ldl_solve(const double (&m)[10], double shift, double tiny,
                                           const double (&b)[4], double (&x)[4]) {
     const double a00 = m[0] - shift, a11 = m[4] - shift, a22 = m[7] - shift, a33 = m[9] - shift;
@@ -227,7 +229,7 @@ __device__ __forceinline__ bool ldl_solve(const double (&m)[10], double shift, d
     const double t32 = fma(-l31, t21, fma(-l30, a02, a23));
     const double l32 = t32 * i2;
     double d3 = fma(-l32, t32, fma(-l31, t31, fma(-l30, a03, a33)));
-    const bool ok = d0 > 0 && d1 > 0 && d2 > 0;
+    const bool ok = d0 > 0 && d1 > 0 && d2 > 0 && d3 > -1e17 * tiny;
     d3 = d3 > tiny ? d3 : tiny;
     const double i3 = 1.0 / d3;
     const double y0 = b[0];
@@ -262,6 +264,7 @@ __device__ __forceinline__ bool null_vector_invit(const double (&At)[4][4], doub
     double x[4] = {0.1, 0.2, 0.9, 0.3};
     double shift = -trace * 1e-15;  // strictly below the spectrum of a positive semidefinite M
     bool done = false, bad = false;
+    double prev_delta = 1.0;
     for (int it = 0; it < kMaxInvIt; ++it) {
         double y[4];
         const bool ok = ldl_solve(m, shift, tiny, x, y);
@@ -285,9 +288,13 @@ __device__ __forceinline__ bool null_vector_invit(const double (&At)[4][4], doub
             for (int k = 0; k < 4; ++k) x[k] = z[k];
             bad |= !ok || !(n2 > 0) || !(n2 < 1e300);
         }
-        // the error is squared per step: a step that moved the iterate by < 1e-7 landed
-        // within ~1e-14 of the eigenvector
-        done |= (it > 0 && delta < 1e-7) || bad;
+        // the moves of two consecutive steps give the contraction q = delta / prev_delta and
+        // the distance left as about delta q / (1 - q): accepted below 1e-10 (or when the
+        // iterate has stopped moving at rounding level); a small move alone says nothing
+        // about the distance left when the moves shrink slowly
+        done |= (it > 0 && delta < 1e-7 &&
+                 (delta <= 1e-13 || delta * delta <= 1e-10 * (prev_delta - delta))) || bad;
+        if (!done) prev_delta = delta;
         if (__all(done)) break;
         // Rayleigh quotient and residual: an eigenvalue lies within |r| of rho; it is the
         // smallest one once the iterate is dominated by that eigenvector

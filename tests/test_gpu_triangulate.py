@@ -253,3 +253,49 @@ def test_triangulate_full_size_10m(ctx, oracle):
     np.testing.assert_allclose(err[sel], oerr, rtol=1e-6, atol=1e-7)
     band = np.abs(oerr - 3.0) < 1e-6
     np.testing.assert_array_equal(mask[sel][~band], omask.astype(bool)[~band])
+
+
+@pytest.mark.parametrize("seed", [242, 243, 244])
+def test_triangulate_short_baseline_with_outliers(ctx, oracle, seed):
+    """A short baseline with many mismatched correspondences: some of them triangulate behind the
+    cameras with the two smallest singular values of their system only a factor 2-3 apart, and
+    a null vector nearly orthogonal to the solver's start vector.  The deferred-point solver must
+    not settle on another singular vector for them (a shift above the smallest eigenvalue shows
+    as a negative LAST pivot of the factorisation); every point with a clear null vector inside
+    1000 units agrees with the oracle to 1e-6 relative, masks are equal."""
+    from sfm_amd import synth
+
+    rng = np.random.default_rng(seed)
+    n = 5003
+    K = np.array([[1000.0, 0, 640], [0, 1000.0, 360], [0, 0, 1]])
+    R = synth.rot_y(1.5)
+    t = np.array([-0.035, 0.01, 0.012])
+    prev_pose = np.hstack([np.eye(3), np.zeros((3, 1))])
+    curr_pose = np.hstack([R, t[:, None]])
+    X = np.empty((n, 3))
+    X[:, 2] = rng.uniform(2.27, 6.46, n)
+    X[:, 0] = rng.uniform(-0.4, 0.4, n) * X[:, 2]
+    X[:, 1] = rng.uniform(-0.3, 0.3, n) * X[:, 2]
+    p1 = X @ K.T
+    p1 = p1[:, :2] / p1[:, 2:]
+    p2 = (X @ R.T + t) @ K.T
+    p2 = p2[:, :2] / p2[:, 2:]
+    out = rng.random(n) < 0.3
+    p2[out] += rng.uniform(-80, 80, (int(out.sum()), 2))
+    p1, p2 = p1.astype(np.float32), p2.astype(np.float32)
+    args = (K, prev_pose, curr_pose, R, t, p1, p2)
+    Xg, _, mask, err = ctx.triangulate(*args)
+    oX, _, omask, oerr = oracle.triangulate(*args)
+    P1, P2 = K @ prev_pose, K @ curr_pose
+    A = np.stack([p1[:, :1] * P1[2] - P1[0], p1[:, 1:] * P1[2] - P1[1],
+                  p2[:, :1] * P2[2] - P2[0], p2[:, 1:] * P2[2] - P2[1]], axis=1)
+    sv = np.linalg.svd(A, compute_uv=False)
+    sel = (sv[:, 3] < 0.5 * sv[:, 2]) & (np.linalg.norm(oX, axis=1) < 1e3)
+    assert sel.sum() > 0.9 * n
+    # the kind of point the case is about is present
+    assert ((sv[:, 3] > 0.2 * sv[:, 2]) & sel & (oX[:, 2] < 0)).sum() > 10
+    rel = np.linalg.norm(Xg - oX, axis=1) / np.linalg.norm(oX, axis=1)
+    assert rel[sel].max() < 1e-6 < TOL_REL
+    np.testing.assert_allclose(err[sel], oerr[sel], rtol=1e-6, atol=1e-8)
+    band = np.abs(oerr - 3.0) < 1e-6
+    np.testing.assert_array_equal(mask[sel & ~band], omask[sel & ~band])
