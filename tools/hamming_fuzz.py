@@ -13,6 +13,7 @@ from sfm_amd import capi  # noqa: E402
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    big = len(sys.argv) > 2 and sys.argv[2] == "big"   # row counts around and above one 8192-row train range
     rng = np.random.default_rng(77)
     ctx = capi.Context(0)
     bad = 0
@@ -20,6 +21,9 @@ def main():
         d = int(rng.choice([1, 7, 13, 16, 31, 32, 33, 61, 64]))
         n_prev = int(rng.choice([1, 2, 3, 63, 64, 65, 500, 1023, 1025, 2049, 4000]))
         n_curr = int(rng.choice([1, 2, 3, 63, 64, 65, 500, 1023, 1025, 2049, 4000]))
+        if big:
+            n_prev = int(rng.choice([500, 8191, 8192, 8193, 12000, 16385, 20000]))
+            n_curr = int(rng.choice([500, 8191, 8192, 8193, 12000, 16385, 20000]))
         kind = int(rng.integers(0, 3))
         if kind == 0:
             a = rng.integers(0, 256, (n_prev, d), dtype=np.uint8)

@@ -13,6 +13,7 @@ from sfm_amd import capi  # noqa: E402
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    big = len(sys.argv) > 2 and sys.argv[2] == "big"   # train sets around and above 8192 rows
     rng = np.random.default_rng(2026)
     ctx = capi.Context(0)
     bad = 0
@@ -20,6 +21,10 @@ def main():
         dim = int(rng.choice([1, 3, 16, 32, 61, 64, 65, 100, 128, 129, 200, 256]))
         nq = int(rng.choice([1, 2, 31, 33, 64, 255, 257, 700, 1500]))
         nt = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 129, 500, 1250, 3000]))
+        if big:
+            nq = int(rng.choice([500, 4097, 9000]))
+            nt = int(rng.choice([8191, 8192, 8193, 12000, 16385, 20000]))
+            dim = int(rng.choice([32, 64, 128]))
         kind = int(rng.integers(0, 5))
         if kind == 0:
             q = rng.standard_normal((nq, dim)).astype(np.float32)
