@@ -19,6 +19,8 @@ def main():
     for case in range(n_cases):
         h = int(rng.integers(3, 300))
         w = int(rng.integers(3, 400))
+        if len(sys.argv) > 2 and sys.argv[2] == "big":   # up to full-HD frames
+            h, w = int(rng.integers(300, 1100)), int(rng.integers(400, 2000))
         kind = int(rng.integers(0, 4))
         if kind == 0 and min(h, w) >= 16:
             img = synth.to_u8(synth.texture(h, w, seed=int(rng.integers(0, 10 ** 6))))
