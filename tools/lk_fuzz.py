@@ -22,6 +22,9 @@ def main():
     for case in range(n_cases):
         h = int(rng.integers(24, 260))
         w = int(rng.integers(24, 330))
+        big = len(sys.argv) > 3 and sys.argv[3] == "big"          # frames up to full HD, thousands of points
+        if big:
+            h, w = int(rng.integers(400, 1100)), int(rng.integers(500, 2000))
         prev, curr = synth.lk_pair(h, w, seed=int(rng.integers(0, 10 ** 6)))
         if rng.integers(0, 4) == 0:       # a flat region: singular normal matrices
             prev[: h // 3, : w // 2] = 90
@@ -35,7 +38,7 @@ def main():
         eps = float(rng.choice([0.0, 0.001, 0.01, 0.3]))
         thr = float(rng.choice([1e-4, 1e-3, 0.0]))
         max_err = float(rng.choice([10.0, 3.0, 1e9]))
-        n = int(rng.integers(1, 400))
+        n = int(rng.integers(1, 400)) if not big else int(rng.integers(500, 4000))
         pts = np.stack([rng.uniform(-5, w + 5, n), rng.uniform(-5, h + 5, n)], 1).astype(np.float32)
         if rng.integers(0, 2):            # points on whole pixels
             pts[: n // 2] = np.round(pts[: n // 2])
