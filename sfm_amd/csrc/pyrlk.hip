@@ -583,6 +583,43 @@ __device__ __forceinline__ void window_interp(const uint8_t* base, unsigned o, i
     window_interp(load_u8x8(base + o), load_u8x8(base + (o + (unsigned)S)), wt, p01, p23, p45, p6);
 }
 
+// ---- derivative windows formed in the tracker (21 x 21 windows) -----------------------------
+// Packed 16-bit helpers: two values per register, as pairs of horizontally adjacent columns.
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ushort2_t, a) + __builtin_bit_cast(ushort2_t, b));
+}
+// a * ka + b * kb per half (all results fit 16 bits; signed and unsigned agree in the low 16 bits)
+template <int KA, int KB>
+__device__ __forceinline__ uint32_t pk_lin_u16(uint32_t a, uint32_t b) {
+    const ushort2_t ka = {(unsigned short)KA, (unsigned short)KA}, kb = {(unsigned short)KB, (unsigned short)KB};
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ushort2_t, a) * ka + __builtin_bit_cast(ushort2_t, b) * kb);
+}
+// bytes 2 W, 2 W + 1 of x as two 16-bit values
+template <int W>
+__device__ __forceinline__ uint32_t unpack_pair(uint32_t x) {
+    return __builtin_amdgcn_perm(0u, x, W ? 0x0C030C02u : 0x0C010C00u);
+}
+// (hi16(lo), lo16(hi)): the pair one column to the right of `lo`
+__device__ __forceinline__ uint32_t next_pair(uint32_t lo, uint32_t hi) {
+    return __builtin_amdgcn_alignbyte(hi, lo, 2);
+}
+
+// The four bilinear weights paired by ROW of the 2x2 footprint (the derivative path holds its
+// values as pairs of adjacent columns).
+struct RowWeights {
+    uint32_t top;  // iw00 | iw01 << 16
+    uint32_t bot;  // iw10 | iw11 << 16
+};
+__device__ __forceinline__ RowWeights row_weights(const Weights& w) {
+    RowWeights r;
+    r.top = __builtin_amdgcn_perm(w.wr, w.wl, 0x05040100u);  // (lo16(wl), lo16(wr))
+    r.bot = __builtin_amdgcn_perm(w.wr, w.wl, 0x07060302u);  // (hi16(wl), hi16(wr))
+    return r;
+}
+__device__ __forceinline__ int footprint_rows(uint32_t top, uint32_t bot, const RowWeights& w, int round) {
+    return sdot2(bot, w.bot, sdot2_k(top, w.top, round));
+}
+
 // LPP = lanes per point: 64 (one point per wave) or 16 (four points per wave, one per
 // DPP row; the per-point scalar work is then shared by four points per instruction).
 // VERT (21 x 21 windows on 16 lanes): a lane's four slots are the same seven columns of four
@@ -590,11 +627,26 @@ __device__ __forceinline__ void window_interp(const uint8_t* base, unsigned o, i
 // lower image row of one slot is the upper row of the next and five row loads serve four
 // slots instead of eight; lane 15 takes the three slots of window row 20 and loads their
 // upper rows by itself.
-template <int LPP, int SPL, bool FULL, bool VERT = false>
-__global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
+// FLY (21 x 21 windows on 16 lanes, the default for them): the vertical layout again, and no
+// derivative image is read.  Scharr and the bilinear interpolation are both exact integer
+// linear maps, so a lane forms the derivatives at the 5 x 8 integer positions its four slots
+// touch from 7 rows of 10 pixels of the level itself (packed 16-bit arithmetic on pairs of
+// adjacent columns), zeroes the positions outside the image, as the derivative image would be
+// there, and interpolates them like loaded ones.  Lanes 0..14 own window rows 0-3, 4-7, 9-12,
+// 13-16, 17-20 of a segment; lane 15 owns the three slots of window row 8, whose two derivative
+// rows are the last one of the group above and the first one of the group below: they and the
+// two pixel rows travel to it through LDS.
+template <int LPP, int SPL, bool FULL, bool VERT = false, bool FLY = false>
+__global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
     static_assert(!VERT || (LPP == 16 && SPL == 4 && FULL), "vertical groups: 21 x 21 windows on 16 lanes");
+    static_assert(!FLY || VERT, "the derivative path builds on the vertical layout");
     const int lane = threadIdx.x & (LPP - 1);
     const bool own_rows = VERT && lane == 15;   // the lane whose slots sit side by side
+    // FLY: first window row and segment of the lane's block (lane 15: a block whose loads stay
+    // inside the level; what it computes from them is replaced)
+    const int fly_row0 = own_rows ? 8 : 4 * (lane / 3) + (lane >= 6 ? 1 : 0);
+    const int fly_seg = own_rows ? 0 : lane % 3;
+    __shared__ uint4 xfer[FLY ? 4 * 4 * 3 * 7 : 1];   // per wave, point, segment: 7 x 16 bytes for lane 15
     // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); give each XCD one
     // contiguous eighth of the points, so that an image pair's pyramids are fetched into
     // one L2 instead of all eight.
@@ -621,6 +673,14 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
     SlotMask<FULL> msk[SPL];
 #pragma unroll
     for (int s = 0; s < SPL; ++s) {
+        if (FLY) {
+            // lane 15: slots 0, 2, 3 are the segments of window row 8; slot 1 does not exist
+            // (it repeats slot 0's place and counts as invalid below)
+            const int srow = own_rows ? 8 : fly_row0 + s;
+            const int sx0 = (own_rows ? max(s - 1, 0) : fly_seg) * kPxPerSlot;
+            sgeom[s] = (srow << 8) | sx0;
+            continue;
+        }
         if (VERT) {
             // lane 15's fourth slot does not exist: it repeats the third one's place (loads stay
             // inside the level) and counts as invalid below
@@ -636,7 +696,9 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
         sgeom[s] = (srow << 8) | sx0;
         msk[s].set(valid ? min(kPxPerSlot, a.win_w - sx0) : 0);
     }
-    auto slot_valid = [&](int s) { return VERT ? !(own_rows && s == 3) : lane + LPP * s < a.slots; };
+    auto slot_valid = [&](int s) {
+        return FLY ? !(own_rows && s == 1) : VERT ? !(own_rows && s == 3) : lane + LPP * s < a.slots;
+    };
     // The rows of all slots of a lane from one image: up[s] / lo[s] are the upper and lower row
     // of slot s.  VERT: five loads by every lane (the first slot's upper row and every slot's
     // lower row) and two more by lane 15 alone.
@@ -648,6 +710,20 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
                 up[s] = load_u8x8(base + (o0 + soff[s]));
                 lo[s] = load_u8x8(base + (o0 + soff[s] + (unsigned)S));
             }
+            return;
+        }
+        if (FLY) {   // lane 15: slots 0, 2, 3 side by side; its slot 1 holds rows of no meaning
+            uint2 x2 = make_uint2(0, 0), x3 = x2;
+            if (own_rows) {
+                x2 = load_u8x8(base + (o0 + soff[2]));
+                x3 = load_u8x8(base + (o0 + soff[3]));
+            }
+            up[0] = load_u8x8(base + (o0 + soff[0]));
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) lo[s] = load_u8x8(base + (o0 + soff[s] + (unsigned)S));
+            up[1] = lo[0];
+            up[2] = own_rows ? x2 : lo[1];
+            up[3] = own_rows ? x3 : lo[2];
             return;
         }
         // lane 15's own loads first, into registers of their own: all seven loads are then in
@@ -712,6 +788,167 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
         const unsigned obase = (unsigned)((ipy + g.bh) * S + ipx + g.bw);
         uint2 iu[SPL], il[SPL];
         uint4 du[SPL][2], dl[SPL][2];   // VERT: the derivative rows of the lane's slots, loaded once
+        if constexpr (FLY) {
+            // 7 rows (window rows fly_row0 - 1 .. + 5) of the 10 pixels from one column left of the
+            // segment, as aligned 16-byte loads (a padded level starts 16-byte aligned and its row
+            // pitch is a multiple of 16); the byte shuffle that widens two pixels to 16 bits each
+            // picks them at the lane's own byte offset.
+            const uint8_t* Ia = I - S - 4;
+            const unsigned ofb = obase + (unsigned)(fly_row0 * S + fly_seg * kPxPerSlot) + 3u;
+            const unsigned oal = ofb & ~3u, sh = (ofb & 3u) * 0x00010001u;
+            // selectors for the bytes (sh + 2k, sh + 2k + 1) of the 16 loaded, from the two dwords that hold them
+            const uint32_t sel0 = 0x0C010C00u + sh, sel1 = 0x0C030C02u + sh, sel2 = 0x0C010C00u + sh,
+                           sel3 = 0x0C030C02u + sh, sel4 = 0x0C010C00u + sh;
+            uint32_t hp[7][5];   // pixel pairs (columns 2k, 2k+1 of the 10 in use)
+            {
+                uint4 raw[7];
+#pragma unroll
+                for (int r = 0; r < 7; ++r)
+                    raw[r] = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(Ia + (oal + (unsigned)(r * S)), 4));
+#pragma unroll
+                for (int r = 0; r < 7; ++r) {
+                    hp[r][0] = __builtin_amdgcn_perm(raw[r].y, raw[r].x, sel0);
+                    hp[r][1] = __builtin_amdgcn_perm(raw[r].y, raw[r].x, sel1);
+                    hp[r][2] = __builtin_amdgcn_perm(raw[r].z, raw[r].y, sel2);
+                    hp[r][3] = __builtin_amdgcn_perm(raw[r].z, raw[r].y, sel3);
+                    hp[r][4] = __builtin_amdgcn_perm(raw[r].w, raw[r].z, sel4);
+                }
+            }
+            // Four times the Scharr derivatives (lkpyramid.cpp calcSharrDeriv) at the block's
+            // 5 rows x 8 columns, as pairs of columns (2m, 2m+1): derivative row i sits at window
+            // row fly_row0 + i, derivative column j at column 7 seg + j, which is column j + 1 of hp.
+            uint32_t dx[5][4], dy[5][4];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                uint32_t sv[5], dv[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    sv[k] = pk_lin_u16<12, 40>(pk_add_u16(hp[i][k], hp[i + 2][k]), hp[i + 1][k]);   // 4 (3, 10, 3)
+                    dv[k] = pk_sub_i16(hp[i + 2][k], hp[i][k]);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    dx[i][m] = pk_sub_i16(sv[m + 1], sv[m]);
+                    dy[i][m] = pk_lin_u16<12, 40>(pk_add_u16(dv[m], dv[m + 1]), next_pair(dv[m], dv[m + 1]));
+                }
+            }
+            // the derivative image is zero outside the image: windows that reach beyond it
+            if (__any(ipx < 0 || ipx + a.win_w + 1 > lw || ipy < 0 || ipy + a.win_h + 1 > lh)) {
+                const int cx0 = ipx + fly_seg * kPxPerSlot, cy0 = ipy + fly_row0;
+                uint32_t cm[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    cm[m] = ((unsigned)(cx0 + 2 * m) < (unsigned)lw ? 0xFFFFu : 0u) |
+                            ((unsigned)(cx0 + 2 * m + 1) < (unsigned)lw ? 0xFFFF0000u : 0u);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const uint32_t rm = (unsigned)(cy0 + i) < (unsigned)lh ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        dx[i][m] &= cm[m] & rm;
+                        dy[i][m] &= cm[m] & rm;
+                    }
+                }
+            }
+            // Window row 8 for lane 15: its upper derivative and pixel rows from the lanes of
+            // rows 4-7 (their row 4 / rows 5, 6 of hp), its lower derivative row from the lanes of
+            // rows 9-12 (their row 0).  A wave's LDS operations complete in order, and every point
+            // has its own 16 lanes and its own part of the array: no barrier.
+            uint4* xq = xfer + ((threadIdx.x >> 4) * 3) * 7;   // this point's three segments
+            if (lane >= 3 && lane < 6) {
+                uint4* q = xq + fly_seg * 7;
+                q[0] = make_uint4(dx[4][0], dx[4][1], dx[4][2], dx[4][3]);
+                q[1] = make_uint4(dy[4][0], dy[4][1], dy[4][2], dy[4][3]);
+                q[4] = make_uint4(hp[5][0], hp[5][1], hp[5][2], hp[5][3]);
+                q[5] = make_uint4(hp[6][0], hp[6][1], hp[6][2], hp[6][3]);
+                q[6] = make_uint4(hp[5][4], hp[6][4], 0u, 0u);
+            }
+            if (lane >= 6 && lane < 9) {
+                uint4* q = xq + fly_seg * 7;
+                q[2] = make_uint4(dx[0][0], dx[0][1], dx[0][2], dx[0][3]);
+                q[3] = make_uint4(dy[0][0], dy[0][1], dy[0][2], dy[0][3]);
+            }
+            // Slot s reads derivative rows s, s + 1 and pixel rows s + 1, s + 2; slot 3's upper rows
+            // are copies, so that lane 15's slots 0, 2, 3 find three separate pairs of rows.
+            uint32_t dx3[4], dy3[4], hp4[5];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                dx3[m] = dx[3][m];
+                dy3[m] = dy[3][m];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) hp4[k] = hp[4][k];
+            if (own_rows) {
+                auto put4 = [](uint32_t (&d)[4], const uint4& v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; };
+                auto put5 = [](uint32_t (&d)[5], const uint4& v, uint32_t e) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; d[4] = e; };
+                const uint4 t0 = xq[6], t1 = xq[7 + 6], t2 = xq[14 + 6];
+                put4(dx[0], xq[0]);      put4(dy[0], xq[1]);      put4(dx[1], xq[2]);      put4(dy[1], xq[3]);
+                put5(hp[1], xq[4], t0.x);                         put5(hp[2], xq[5], t0.y);
+                put4(dx[2], xq[7 + 0]);  put4(dy[2], xq[7 + 1]);  put4(dx[3], xq[7 + 2]);  put4(dy[3], xq[7 + 3]);
+                put5(hp[3], xq[7 + 4], t1.x);                     put5(hp[4], xq[7 + 5], t1.y);
+                put4(dx3, xq[14 + 0]);   put4(dy3, xq[14 + 1]);   put4(dx[4], xq[14 + 2]); put4(dy[4], xq[14 + 3]);
+                put5(hp4, xq[14 + 4], t2.x);                      put5(hp[5], xq[14 + 5], t2.y);
+            }
+            const RowWeights rw = row_weights(wt);
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                SlotWin& w = win[s];
+                const uint32_t(&ht)[5] = s == 3 ? hp4 : hp[s + 1];
+                const uint32_t(&hb)[5] = hp[s + 2];
+                const uint32_t(&xt)[4] = s == 3 ? dx3 : dx[s];
+                const uint32_t(&yt)[4] = s == 3 ? dy3 : dy[s];
+                const uint32_t(&xb)[4] = dx[s + 1];
+                const uint32_t(&yb)[4] = dy[s + 1];
+                // window pixel j has its footprint at columns j + 1, j + 2 of hp
+                constexpr int kRound = 1 << (W_BITS - 5 - 1);
+                int si[kPxPerSlot];
+#pragma unroll
+                for (int j = 0; j < kPxPerSlot; ++j) {
+                    const int k = (j + 1) >> 1;
+                    const uint32_t top = (j & 1) ? ht[k] : next_pair(ht[k], ht[k + 1]);
+                    const uint32_t bot = (j & 1) ? hb[k] : next_pair(hb[k], hb[k + 1]);
+                    si[j] = footprint_rows(top, bot, rw, kRound);
+                }
+                w.i01 = pack_shr9(si[0], si[1]);
+                w.i23 = pack_shr9(si[2], si[3]);
+                w.i45 = pack_shr9(si[4], si[5]);
+                w.i6 = si[6] >> (W_BITS - 5);
+                // derivative of window pixel j from derivative columns j, j + 1
+                int sx[kPxPerSlot], sy[kPxPerSlot];
+#pragma unroll
+                for (int j = 0; j < kPxPerSlot; ++j) {
+                    const int m = j >> 1;
+                    const uint32_t xtp = (j & 1) ? next_pair(xt[m], xt[m + 1]) : xt[m];
+                    const uint32_t xbp = (j & 1) ? next_pair(xb[m], xb[m + 1]) : xb[m];
+                    const uint32_t ytp = (j & 1) ? next_pair(yt[m], yt[m + 1]) : yt[m];
+                    const uint32_t ybp = (j & 1) ? next_pair(yb[m], yb[m + 1]) : yb[m];
+                    sx[j] = footprint_rows(xtp, xbp, rw, 1 << (W_BITS + 1));
+                    sy[j] = footprint_rows(ytp, ybp, rw, 1 << (W_BITS + 1));
+                }
+                w.x01 = pack_hi16(sx[0], sx[1]);
+                w.x23 = pack_hi16(sx[2], sx[3]);
+                w.x45 = pack_hi16(sx[4], sx[5]);
+                w.x6 = sx[6] >> 16;
+                w.y01 = pack_hi16(sy[0], sy[1]);
+                w.y23 = pack_hi16(sy[2], sy[3]);
+                w.y45 = pack_hi16(sy[4], sy[5]);
+                w.y6 = sy[6] >> 16;
+                if (s == 1) {   // lane 15's slot 1 does not exist: no derivatives, no contribution
+                    const uint32_t keep = own_rows ? 0u : 0xFFFFFFFFu;
+                    w.x01 &= keep;
+                    w.x23 &= keep;
+                    w.x45 &= keep;
+                    w.x6 &= (int)keep;
+                    w.y01 &= keep;
+                    w.y23 &= keep;
+                    w.y45 &= keep;
+                    w.y6 &= (int)keep;
+                }
+                pA[0] = mad24(w.x6, w.x6, sdot2(w.x45, w.x45, sdot2(w.x23, w.x23, sdot2(w.x01, w.x01, pA[0]))));
+                pA[1] = mad24(w.x6, w.y6, sdot2(w.x45, w.y45, sdot2(w.x23, w.y23, sdot2(w.x01, w.y01, pA[1]))));
+                pA[2] = mad24(w.y6, w.y6, sdot2(w.y45, w.y45, sdot2(w.y23, w.y23, sdot2(w.y01, w.y01, pA[2]))));
+            }
+        } else {
         if (VERT) {
             load_rows8(I, obase, soff, S, iu, il);
             auto load_d = [&](unsigned o, uint4 (&r)[2]) { __builtin_memcpy(r, D + o, 32); };
@@ -808,6 +1045,7 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LkArgs a) {
             pA[1] = mad24(w.x6, w.y6, sdot2(w.x45, w.y45, sdot2(w.x23, w.y23, sdot2(w.x01, w.y01, pA[1]))));
             pA[2] = mad24(w.y6, w.y6, sdot2(w.y45, w.y45, sdot2(w.y23, w.y23, sdot2(w.y01, w.y01, pA[2]))));
         }
+        }   // !FLY
         float A11, A12, A22;
         if (LPP == 64) {
             long long sA[3];
@@ -970,9 +1208,11 @@ int make_geom(int width, int height, int win_w, int win_h, int max_level, LkGeom
         g->h[l] = h;
         // 8 extra columns: a slot's 8-element loads may run past the window
         g->stride[l] = (int)align_up((size_t)w + g->bw + win_w + 8, 16);
-        // every padded row starts 16-byte aligned (off is a multiple of 64)
-        g->img_off[l] = off + (size_t)win_h * g->stride[l] + (size_t)g->bw;
-        off = align_up(g->img_off[l] - g->bw + (size_t)(h + win_h) * g->stride[l] + 64, 64);
+        // every padded row starts 16-byte aligned (off is a multiple of 64).  One row of slack
+        // above and below the padded level: the tracker's derivative path reads a ring of one
+        // pixel around the window's footprint (what it reads there never reaches a result).
+        g->img_off[l] = off + (size_t)(win_h + 1) * g->stride[l] + (size_t)g->bw;
+        off = align_up(g->img_off[l] - g->bw + (size_t)(h + win_h + 1) * g->stride[l] + 64, 64);
         w = (w + 1) / 2;
         h = (h + 1) / 2;
     }
@@ -994,10 +1234,21 @@ struct LkBuffers {
     uint32_t* deriv;
 };
 
-size_t lk_carve(Carver& c, const LkGeom& g, int n_pairs, LkBuffers* b) {
+// 21 x 21 windows: the tracker forms the derivatives itself (lk_track_kernel<16, 4, true, true,
+// true>) and no derivative image exists.  SFM_LK_DERIV_IMAGE=1 (a measurement aid) selects the
+// kernel that reads one.
+bool lk_needs_deriv_image(int win_w, int win_h) {
+    static const bool forced = [] {
+        const char* e = getenv("SFM_LK_DERIV_IMAGE");
+        return e && e[0] == '1';
+    }();
+    return forced || win_w != 21 || win_h != 21;
+}
+
+size_t lk_carve(Carver& c, const LkGeom& g, int n_pairs, bool deriv, LkBuffers* b) {
     b->pyr_prev = c.take<uint8_t>(g.block * n_pairs);
     b->pyr_curr = c.take<uint8_t>(g.block * n_pairs);
-    b->deriv = c.take<uint32_t>(g.block * n_pairs);
+    b->deriv = deriv ? c.take<uint32_t>(g.block * n_pairs) : nullptr;
     return c.total();
 }
 
@@ -1094,7 +1345,7 @@ size_t sfm_pyrlk_workspace(int n_pairs, int width, int height, int win_w, int wi
     make_geom(width, height, win_w, win_h, max_level, &g);
     Carver c(nullptr);
     LkBuffers b;
-    return lk_carve(c, g, n_pairs, &b);
+    return lk_carve(c, g, n_pairs, lk_needs_deriv_image(win_w, win_h), &b);
 }
 
 int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_curr, int n_pairs,
@@ -1129,11 +1380,12 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     const LkGeom& g = a.g;
     Carver sz(nullptr);
     LkBuffers bufs;
-    const size_t need = lk_carve(sz, g, n_pairs, &bufs);
+    const bool deriv_image = lk_needs_deriv_image(win_w, win_h);
+    const size_t need = lk_carve(sz, g, n_pairs, deriv_image, &bufs);
     void* ws;
     SFM_RETURN_IF(workspace(ctx, need, &ws));
     Carver c(ws);
-    lk_carve(c, g, n_pairs, &bufs);
+    lk_carve(c, g, n_pairs, deriv_image, &bufs);
 
     const dim3 blk(256);
     {
@@ -1152,7 +1404,7 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
                            bufs.pyr_curr);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
-    {
+    if (deriv_image) {
         const int S = g.stride[0];
         // four groups per thread at level 0: workgroups that find nothing to do at the smaller
         // levels are then a small part of the launch
@@ -1203,7 +1455,9 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
             hipLaunchKernelGGL((lk_track_kernel<LPP_, SPL_, false>), grid, blk, 0, ctx->stream, a);   \
     } while (0)
         static const bool no_vert = getenv("SFM_LK_NO_VERT") != nullptr;   // measurement aid
-        if (a.win_w == 21 && a.win_h == 21 && !no_vert) {
+        if (!deriv_image) {
+            hipLaunchKernelGGL((lk_track_kernel<16, 4, true, true, true>), grid, blk, 0, ctx->stream, a);
+        } else if (a.win_w == 21 && a.win_h == 21 && !no_vert) {
             hipLaunchKernelGGL((lk_track_kernel<16, 4, true, true>), grid, blk, 0, ctx->stream, a);
         } else
         switch ((a.slots + 15) / 16) {

@@ -553,7 +553,13 @@ void set_cameras(TriArgs& a, const double* K, const double* prev_pose, const dou
     a.cy = K[5];
 }
 
-int run_triangulation(sfm_ctx* ctx, TriArgs& a);
+struct TriLists;
+int run_triangulation(sfm_ctx* ctx, TriArgs& a, const TriLists* fixed);
+int point_list_args(sfm_ctx* ctx, const double* K, const double* prev_pose, const double* curr_pose,
+                    const double* R, const double* t, const float* d_prev_pts, const float* d_curr_pts, int n,
+                    const uint8_t* d_bgr, int img_w, int img_h, size_t img_stride, float min_dist, float max_dist,
+                    float max_proj_err, double* d_X, uint8_t* d_rgb, uint8_t* d_mask, double* d_err, TriArgs* out,
+                    bool* nothing_to_do);
 
 // ---- cv::recoverPose -------------------------------------------------------------------------
 // (Tracking::findCameraPose, Source Files/tracking.cpp:110): decomposeEssentialMat gives two
@@ -911,31 +917,13 @@ int sfm_triangulate_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
                         const uint8_t* d_bgr, int img_w, int img_h, size_t img_stride,
                         float min_dist, float max_dist, float max_proj_err, double* d_X,
                         uint8_t* d_rgb, uint8_t* d_mask, double* d_err) {
-    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
-    if (n < 0) return set_error(ctx, SFM_E_INVALID, "negative point count");
-    if (n == 0) return SFM_OK;  // reconstruction.cpp:42
-    if (!K || !prev_pose || !curr_pose || !R || !t || !d_prev_pts || !d_curr_pts || !d_X || !d_mask)
-        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
-    if (d_bgr && (!d_rgb || img_w <= 0 || img_h <= 0 || img_stride < (size_t)img_w * 3))
-        return set_error(ctx, SFM_E_INVALID, "bad colour image description");
-    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     TriArgs a{};
-    set_cameras(a, K, prev_pose, curr_pose, R, t);
-    a.prev_pts = reinterpret_cast<const float2*>(d_prev_pts);
-    a.curr_pts = reinterpret_cast<const float2*>(d_curr_pts);
-    a.n = n;
-    a.bgr = d_bgr;
-    a.img_w = img_w;
-    a.img_h = img_h;
-    a.img_stride = img_stride;
-    a.min_dist = (double)min_dist;
-    a.max_dist = (double)max_dist;
-    a.max_err = (double)max_proj_err;
-    a.X = d_X;
-    a.rgb = d_rgb;
-    a.mask = d_mask;
-    a.err = d_err;
-    return run_triangulation(ctx, a);
+    bool nothing_to_do = false;
+    SFM_RETURN_IF(point_list_args(ctx, K, prev_pose, curr_pose, R, t, d_prev_pts, d_curr_pts, n, d_bgr, img_w,
+                                  img_h, img_stride, min_dist, max_dist, max_proj_err, d_X, d_rgb, d_mask, d_err,
+                                  &a, &nothing_to_do));
+    if (nothing_to_do) return SFM_OK;  // reconstruction.cpp:42
+    return run_triangulation(ctx, a, nullptr);
 }
 
 int sfm_triangulate_matches_dev(sfm_ctx* ctx, const double* K, const double* prev_pose,
@@ -977,7 +965,7 @@ int sfm_triangulate_matches_dev(sfm_ctx* ctx, const double* K, const double* pre
     a.rgb = d_rgb;
     a.mask = d_mask;
     a.err = d_err;
-    return run_triangulation(ctx, a);
+    return run_triangulation(ctx, a, nullptr);
 }
 
 }  // extern "C"
@@ -997,7 +985,8 @@ static __device__ __align__(256) int scratch[kNoAllocInts];
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 int* g_scratch_ptr[kMaxDevices];        // device address of `scratch` on device d, once known
-hipError_t g_scratch_rc[kMaxDevices];   // why it is not known (hipSuccess: not asked yet)
+bool g_scratch_asked[kMaxDevices];      // the lookup ran on device d (it runs at context creation)
+hipError_t g_scratch_rc[kMaxDevices];   // what the lookup returned when it did not yield an address
 
 // Lists and counters of one launch pair.
 struct TriLists {
@@ -1037,18 +1026,27 @@ void list_geometry(int n, TriLists* l) {
     l->bin_cap = ((blocks + kListBins - 1) / kListBins) * 256;
 }
 
-int run_triangulation(sfm_ctx* ctx, TriArgs& a) {
+// fixed == nullptr: the lists are carved from the context's workspace and the launches are
+// covered by sfm_ctx_set_profiling; otherwise `fixed` holds the list memory to use and nothing
+// is allocated and no event is created.  SFM_TRIANGULATE_JACOBI=1 (a measurement aid) sends
+// every point through the one-sided Jacobi kernel, which needs no lists, on either route.
+int run_triangulation(sfm_ctx* ctx, TriArgs& a, const TriLists* fixed) {
     const int n = a.n;
     static const bool force_jacobi = [] {
         const char* e = getenv("SFM_TRIANGULATE_JACOBI");
         return e && e[0] == '1';
     }();
     if (force_jacobi) {
-        KernelTimer timer(ctx, KID_TRIANGULATE_DLT);
-        hipLaunchKernelGGL(triangulate_dlt_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
+        if (fixed) {
+            hipLaunchKernelGGL(triangulate_dlt_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
+        } else {
+            KernelTimer timer(ctx, KID_TRIANGULATE_DLT);
+            hipLaunchKernelGGL(triangulate_dlt_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
+        }
         SFM_HIP_CHECK(ctx, hipGetLastError());
         return SFM_OK;
     }
+    if (fixed) return launch_triangulation(ctx, a, *fixed, false);
     TriLists l;
     list_geometry(n, &l);
     Carver sz(nullptr);
@@ -1060,6 +1058,44 @@ int run_triangulation(sfm_ctx* ctx, TriArgs& a) {
     l.bin_count = c.take<int>(kListBins);
     l.list = c.take<int>((size_t)l.bins * l.bin_cap);
     return launch_triangulation(ctx, a, l, true);
+}
+
+// Argument checks and kernel arguments shared by sfm_triangulate_dev and
+// sfm_triangulate_noalloc_dev (two point lists on the device).
+int point_list_args(sfm_ctx* ctx, const double* K, const double* prev_pose, const double* curr_pose,
+                    const double* R, const double* t, const float* d_prev_pts, const float* d_curr_pts, int n,
+                    const uint8_t* d_bgr, int img_w, int img_h, size_t img_stride, float min_dist, float max_dist,
+                    float max_proj_err, double* d_X, uint8_t* d_rgb, uint8_t* d_mask, double* d_err, TriArgs* out,
+                    bool* nothing_to_do) {
+    *nothing_to_do = false;
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (n < 0) return set_error(ctx, SFM_E_INVALID, "negative point count");
+    if (n == 0) {
+        *nothing_to_do = true;
+        return SFM_OK;
+    }
+    if (!K || !prev_pose || !curr_pose || !R || !t || !d_prev_pts || !d_curr_pts || !d_X || !d_mask)
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (d_bgr && (!d_rgb || img_w <= 0 || img_h <= 0 || img_stride < (size_t)img_w * 3))
+        return set_error(ctx, SFM_E_INVALID, "bad colour image description");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    TriArgs& a = *out;
+    set_cameras(a, K, prev_pose, curr_pose, R, t);
+    a.prev_pts = reinterpret_cast<const float2*>(d_prev_pts);
+    a.curr_pts = reinterpret_cast<const float2*>(d_curr_pts);
+    a.n = n;
+    a.bgr = d_bgr;
+    a.img_w = img_w;
+    a.img_h = img_h;
+    a.img_stride = img_stride;
+    a.min_dist = (double)min_dist;
+    a.max_dist = (double)max_dist;
+    a.max_err = (double)max_proj_err;
+    a.X = d_X;
+    a.rgb = d_rgb;
+    a.mask = d_mask;
+    a.err = d_err;
+    return SFM_OK;
 }
 
 }  // namespace
@@ -1074,6 +1110,7 @@ void triangulate_scratch_setup(int device) {
     if (g_scratch_ptr[device]) return;
     int* ptr = nullptr;
     const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    g_scratch_asked[device] = true;
     if (e == hipSuccess && ptr) {
         g_scratch_ptr[device] = ptr;
         g_scratch_rc[device] = hipSuccess;
@@ -1094,51 +1131,39 @@ int sfm_triangulate_noalloc_dev(sfm_ctx* ctx, const double* K, const double* pre
                                 const uint8_t* d_bgr, int img_w, int img_h, size_t img_stride,
                                 float min_dist, float max_dist, float max_proj_err, double* d_X,
                                 uint8_t* d_rgb, uint8_t* d_mask, double* d_err) {
-    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
-    if (n < 0) return set_error(ctx, SFM_E_INVALID, "negative point count");
-    if (n > kNoAllocMaxPoints)
+    if (ctx && n > kNoAllocMaxPoints)
         return set_error(ctx, SFM_E_INVALID,
                          "sfm_triangulate_noalloc_dev: %d correspondences exceed the fixed scratch "
                          "(at most %d per call; use sfm_triangulate_dev)", n, kNoAllocMaxPoints);
-    if (n == 0) return SFM_OK;
-    if (!K || !prev_pose || !curr_pose || !R || !t || !d_prev_pts || !d_curr_pts || !d_X || !d_mask)
-        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
-    if (d_bgr && (!d_rgb || img_w <= 0 || img_h <= 0 || img_stride < (size_t)img_w * 3))
-        return set_error(ctx, SFM_E_INVALID, "bad colour image description");
+    TriArgs a{};
+    bool nothing_to_do = false;
+    SFM_RETURN_IF(point_list_args(ctx, K, prev_pose, curr_pose, R, t, d_prev_pts, d_curr_pts, n, d_bgr, img_w,
+                                  img_h, img_stride, min_dist, max_dist, max_proj_err, d_X, d_rgb, d_mask, d_err,
+                                  &a, &nothing_to_do));
+    if (nothing_to_do) return SFM_OK;
     if (ctx->device < 0 || ctx->device >= kMaxDevices)
-        return set_error(ctx, SFM_E_UNSUPPORTED, "device %d has no scratch slot", ctx->device);
+        return set_error(ctx, SFM_E_UNSUPPORTED, "device %d has no scratch slot (devices 0..%d have one)",
+                         ctx->device, kMaxDevices - 1);
     int* ptr;
+    bool asked;
     hipError_t why;
     {
         std::lock_guard<std::mutex> lock(g_scratch_mutex);
         ptr = g_scratch_ptr[ctx->device];
+        asked = g_scratch_asked[ctx->device];
         why = g_scratch_rc[ctx->device];
     }
+    if (!ptr && !asked)
+        return set_error(ctx, SFM_E_HIP, "the scratch array was never looked up on device %d "
+                         "(the look-up runs in sfm_ctx_create*)", ctx->device);
     if (!ptr)
         return set_error(ctx, SFM_E_HIP, "hipGetSymbolAddress(scratch) failed on device %d: %s",
                          ctx->device, hipGetErrorString(why));
-    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    TriArgs a{};
-    set_cameras(a, K, prev_pose, curr_pose, R, t);
-    a.prev_pts = reinterpret_cast<const float2*>(d_prev_pts);
-    a.curr_pts = reinterpret_cast<const float2*>(d_curr_pts);
-    a.n = n;
-    a.bgr = d_bgr;
-    a.img_w = img_w;
-    a.img_h = img_h;
-    a.img_stride = img_stride;
-    a.min_dist = (double)min_dist;
-    a.max_dist = (double)max_dist;
-    a.max_err = (double)max_proj_err;
-    a.X = d_X;
-    a.rgb = d_rgb;
-    a.mask = d_mask;
-    a.err = d_err;
     TriLists l;
     list_geometry(n, &l);
     l.bin_count = ptr;              // cleared by launch_triangulation: the array keeps the
     l.list = ptr + kListBins;       // last call's contents
-    return launch_triangulation(ctx, a, l, false);
+    return run_triangulation(ctx, a, &l);
 }
 
 }  // extern "C"
