@@ -187,15 +187,17 @@ int sfm_gather_segments_dev(sfm_ctx* ctx, const void* d_src, const int64_t* d_sr
  * OpenCV's default minEigThreshold 1e-4.  Points are interleaved (x, y) floats.
  * err (may be NULL) receives the per-point residual.  The normal-equation sums
  * are accumulated exactly in integers (OpenCV: float, build-dependent order).
- * Windows up to 41x41 are supported. */
+ * Windows up to 41x41 are supported.  The two images may have different row pitches, as
+ * calc accepts them (one of them a region of a larger image): prev_stride and curr_stride are
+ * the bytes between rows of each. */
 int sfm_pyrlk(sfm_ctx* ctx, const uint8_t* prev, const uint8_t* curr, int width, int height,
-              size_t stride, const float* prev_pts, int n, int win_w, int win_h,
+              size_t prev_stride, size_t curr_stride, const float* prev_pts, int n, int win_w, int win_h,
               int max_level, int crit_type, int max_count, double epsilon,
               double min_eig_threshold, float max_error, float* curr_pts, uint8_t* status,
               float* err);
 
 /* Batched device form: n_pairs image pairs, pair p at d_prev + p*image_stride /
- * d_curr + p*image_stride (rows `stride` bytes apart), n points per pair at
+ * d_curr + p*image_stride (rows `stride` bytes apart in both), n points per pair at
  * d_prev_pts + p*n*2.  Outputs are laid out likewise. */
 int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_curr,
                         int n_pairs, size_t image_stride, int width, int height,
@@ -205,6 +207,30 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
                         uint8_t* d_status, float* d_err);
 size_t sfm_pyrlk_workspace(int n_pairs, int width, int height, int win_w, int win_h,
                            int max_level);
+
+/* The same in two steps, for sequences: the reference tracks frame k -> k+1 on every
+ * iteration (Source Files/app_solver.cpp:68, :366), so frame k+1's pyramid serves as the next
+ * image of one call and as the previous image of the following one.  OpenCV offers this split as
+ * cv::buildOpticalFlowPyramid + calc on pyramids; the reference does not use it.
+ * sfm_lk_build_pyramids_dev writes one pyramid (every level with its reflect-101 border) per
+ * frame, sfm_lk_pyramid_bytes() bytes each, back to back into caller-owned device memory
+ * (16-byte aligned); frame f at d_frames + f*image_stride, rows `stride` bytes apart.  A pyramid
+ * depends on the image size, the window and max_level, and is valid for any later call with the
+ * same values. */
+size_t sfm_lk_pyramid_bytes(int width, int height, int win_w, int win_h, int max_level);
+int sfm_lk_build_pyramids_dev(sfm_ctx* ctx, const uint8_t* d_frames, int n_frames, size_t image_stride,
+                              int width, int height, size_t stride, int win_w, int win_h, int max_level,
+                              uint8_t* d_pyramids);
+/* sfm_pyrlk_batch_dev on pyramids that exist: pair p tracks its n points from pyramid
+ * d_pairs[2p] to pyramid d_pairs[2p+1] of the n_pyramids in d_pyramids (d_pairs: device array of
+ * int32; an index outside [0, n_pyramids) is clamped into it).  Results are bit-identical to
+ * sfm_pyrlk_batch_dev on the frames the pyramids were built from. */
+int sfm_pyrlk_pyramids_dev(sfm_ctx* ctx, const uint8_t* d_pyramids, int n_pyramids, const int32_t* d_pairs,
+                           int n_pairs, int width, int height, const float* d_prev_pts, int n, int win_w,
+                           int win_h, int max_level, int crit_type, int max_count, double epsilon,
+                           double min_eig_threshold, float max_error, float* d_curr_pts, uint8_t* d_status,
+                           float* d_err);
+size_t sfm_pyrlk_pyramids_workspace(int n_pairs, int width, int height, int win_w, int win_h, int max_level);
 
 /* The filters between computeFlow and findCameraPose (ProcesingAdds::filterPointsByStatusMask
  * and filterPointsByBoundary, Source Files/feature_processing.cpp:332-358, called at

@@ -363,11 +363,12 @@ public:
         if (!mat_is_u8(imPrevGray) || mat_channels(imPrevGray) != 1 || !mat_is_u8(imCurrGray) ||
             mat_channels(imCurrGray) != 1)
             raise("computeFlow needs 8-bit single-channel images");
-        if (imPrevGray.rows != imCurrGray.rows || imPrevGray.cols != imCurrGray.cols ||
-            mat_step(imPrevGray) != mat_step(imCurrGray))
-            raise("computeFlow needs two images of one size and row pitch");
+        if (imPrevGray.rows != imCurrGray.rows || imPrevGray.cols != imCurrGray.cols)
+            raise("computeFlow needs two images of one size");
+        /* the row pitches may differ (one image a region of a larger one), as calc accepts */
         handle.check(sfm_pyrlk(handle.get(), imPrevGray.data, imCurrGray.data, imPrevGray.cols, imPrevGray.rows,
-                               mat_step(imPrevGray), reinterpret_cast<const float*>(prevPts.data()), int(n),
+                               mat_step(imPrevGray), mat_step(imCurrGray),
+                               reinterpret_cast<const float*>(prevPts.data()), int(n),
                                optFlow.winSize.width, optFlow.winSize.height, optFlow.maxLevel,
                                int(optFlow.criteria.type), optFlow.criteria.maxCount, optFlow.criteria.epsilon,
                                optFlow.minEigThreshold, additionalSettings.maxError,
@@ -638,12 +639,11 @@ public:
         status.create(n, 1, CV_8U, -1, true);
         if (err.needed()) err.create(n, 1, CV_32F, -1, true);
         if (n == 0) return;
-        if (prev.type() != CV_8UC1 || next.type() != CV_8UC1 || prev.rows != next.rows || prev.cols != next.cols ||
-            prev.step[0] != next.step[0])
-            CV_Error(cv::Error::StsBadArg, "HipSparsePyrLK: two 8-bit single-channel images of one size and pitch");
+        if (prev.type() != CV_8UC1 || next.type() != CV_8UC1 || prev.rows != next.rows || prev.cols != next.cols)
+            CV_Error(cv::Error::StsBadArg, "HipSparsePyrLK: two 8-bit single-channel images of one size");
         cv::Mat out = nextPts.getMat(), st = status.getMat(), er = err.needed() ? err.getMat() : cv::Mat();
         /* no error gate here: OptFlow::computeFlow applies its own (feature_processing.cpp:245-248) */
-        handle_.check(sfm_pyrlk(handle_.get(), prev.data, next.data, prev.cols, prev.rows, prev.step[0],
+        handle_.check(sfm_pyrlk(handle_.get(), prev.data, next.data, prev.cols, prev.rows, prev.step[0], next.step[0],
                                 pts.ptr<float>(), n, winSize_.width, winSize_.height, maxLevel_, crit_.type,
                                 crit_.maxCount, crit_.epsilon, minEig_, 3.402823466e+38f, out.ptr<float>(),
                                 st.ptr<unsigned char>(), er.empty() ? nullptr : er.ptr<float>()),

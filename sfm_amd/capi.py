@@ -35,6 +35,7 @@ EXPORTS = [
     "sfm_match_pairs_dev", "sfm_match_pairs_workspace",
     "sfm_match_pairs_compact_dev", "sfm_match_pairs_compact_workspace", "sfm_gather_segments_dev",
     "sfm_pyrlk", "sfm_pyrlk_batch_dev", "sfm_pyrlk_workspace",
+    "sfm_lk_pyramid_bytes", "sfm_lk_build_pyramids_dev", "sfm_pyrlk_pyramids_dev", "sfm_pyrlk_pyramids_workspace",
     "sfm_triangulate", "sfm_triangulate_dev", "sfm_triangulate_matches_dev",
     "sfm_triangulate_noalloc_dev", "sfm_triangulate_noalloc_max_points",
     "sfm_fundamental", "sfm_fundamental_dev", "sfm_fundamental_workspace",
@@ -71,7 +72,8 @@ def lib():
         l.sfm_profile_kernel_name.restype = C.c_char_p
         l.sfm_ctx_destroy.restype = None
         l.sfm_ctx_destroy.argtypes = [C.c_void_p]
-        for name in ("sfm_match_pairs_workspace", "sfm_match_pairs_compact_workspace", "sfm_pyrlk_workspace", "sfm_fundamental_workspace",
+        for name in ("sfm_match_pairs_workspace", "sfm_match_pairs_compact_workspace", "sfm_pyrlk_workspace",
+                     "sfm_lk_pyramid_bytes", "sfm_pyrlk_pyramids_workspace", "sfm_fundamental_workspace",
                      "sfm_epipolar_filter_pairs_workspace", "sfm_good_features_workspace", "sfm_good_features_batch_workspace", "sfm_find_essential_workspace", "sfm_recover_pose_workspace",
                      "sfm_find_camera_pose_workspace"):
             if hasattr(l, name):
@@ -245,11 +247,12 @@ class Context:
         prev, curr = np.asarray(prev, dtype=np.uint8), np.asarray(curr, dtype=np.uint8)
         if prev.ndim != 2 or prev.shape != curr.shape:
             raise ValueError("images must be equal-size 8-bit single-channel arrays")
-        # rows may be a view into a wider image (a cv::Mat region of interest) as long as both
-        # images share one row pitch; anything else is made dense first
-        if not (prev.strides[1] == 1 and curr.strides[1] == 1 and
-                prev.strides[0] == curr.strides[0] >= prev.shape[1]):
-            prev, curr = np.ascontiguousarray(prev), np.ascontiguousarray(curr)
+        # rows may be a view into a wider image (a cv::Mat region of interest), each image with
+        # its own row pitch; anything else is made dense first
+        if not (prev.strides[1] == 1 and prev.strides[0] >= prev.shape[1]):
+            prev = np.ascontiguousarray(prev)
+        if not (curr.strides[1] == 1 and curr.strides[0] >= curr.shape[1]):
+            curr = np.ascontiguousarray(curr)
         h, w = prev.shape
         pts = np.ascontiguousarray(prev_pts, dtype=np.float32).reshape(-1, 2)
         n = pts.shape[0]
@@ -258,7 +261,7 @@ class Context:
         err = np.zeros(n, np.float32)
         self.check(lib().sfm_pyrlk(
             self._h, _ptr(prev), _ptr(curr), C.c_int(w), C.c_int(h), C.c_size_t(prev.strides[0]),
-            _ptr(pts), C.c_int(n), C.c_int(win[0]), C.c_int(win[1]), C.c_int(max_level),
+            C.c_size_t(curr.strides[0]), _ptr(pts), C.c_int(n), C.c_int(win[0]), C.c_int(win[1]), C.c_int(max_level),
             C.c_int(crit_type), C.c_int(max_count), C.c_double(epsilon),
             C.c_double(min_eig_threshold), C.c_float(max_error), _ptr(out), _ptr(status),
             _ptr(err)))
@@ -273,6 +276,31 @@ class Context:
             C.c_int(win[0]), C.c_int(win[1]), C.c_int(max_level), C.c_int(crit_type),
             C.c_int(max_count), C.c_double(epsilon), C.c_double(min_eig_threshold),
             C.c_float(max_error), _ptr(d_curr_pts), _ptr(d_status), _ptr(d_err)))
+
+    @staticmethod
+    def lk_pyramid_bytes(width, height, win, max_level):
+        return int(lib().sfm_lk_pyramid_bytes(C.c_int(width), C.c_int(height), C.c_int(win[0]), C.c_int(win[1]),
+                                              C.c_int(max_level)))
+
+    def lk_build_pyramids_dev(self, d_frames, n_frames, image_stride, width, height, stride, win, max_level,
+                              d_pyramids):
+        self.check(lib().sfm_lk_build_pyramids_dev(
+            self._h, _ptr(d_frames), C.c_int(n_frames), C.c_size_t(image_stride), C.c_int(width), C.c_int(height),
+            C.c_size_t(stride), C.c_int(win[0]), C.c_int(win[1]), C.c_int(max_level), _ptr(d_pyramids)))
+
+    def pyrlk_pyramids_dev(self, d_pyramids, n_pyramids, d_pairs, n_pairs, width, height, d_prev_pts, n, win,
+                           max_level, crit_type, max_count, epsilon, min_eig_threshold, max_error, d_curr_pts,
+                           d_status, d_err):
+        self.check(lib().sfm_pyrlk_pyramids_dev(
+            self._h, _ptr(d_pyramids), C.c_int(n_pyramids), _ptr(d_pairs), C.c_int(n_pairs), C.c_int(width),
+            C.c_int(height), _ptr(d_prev_pts), C.c_int(n), C.c_int(win[0]), C.c_int(win[1]), C.c_int(max_level),
+            C.c_int(crit_type), C.c_int(max_count), C.c_double(epsilon), C.c_double(min_eig_threshold),
+            C.c_float(max_error), _ptr(d_curr_pts), _ptr(d_status), _ptr(d_err)))
+
+    @staticmethod
+    def pyrlk_pyramids_workspace(n_pairs, width, height, win, max_level):
+        return int(lib().sfm_pyrlk_pyramids_workspace(C.c_int(n_pairs), C.c_int(width), C.c_int(height),
+                                                      C.c_int(win[0]), C.c_int(win[1]), C.c_int(max_level)))
 
     @staticmethod
     def pyrlk_workspace(n_pairs, width, height, win, max_level):

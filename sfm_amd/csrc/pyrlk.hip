@@ -71,14 +71,16 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 
 // ---- pyramid construction ---------------------------------------------------
 
-// Level 0 of both images of every pair: copy with a reflect-101 border.
-// grid.z = 2*n_pairs (even: previous image, odd: next image).  One thread writes
-// 16 bytes; in the interior that is one unaligned 16-byte load and one store.
+// Level 0 of every image: copy with a reflect-101 border.  two_sets: grid.z = 2 * n_pairs
+// (even: previous image, odd: next image, each set with its own row pitch); otherwise grid.z =
+// number of images of the first set.  One thread writes 16 bytes; in the interior that is one
+// unaligned 16-byte load and one store.
 __global__ void lk_pad_level0_kernel(const uint8_t* __restrict__ prev,
                                      const uint8_t* __restrict__ curr, size_t image_stride,
-                                     size_t row_stride, LkGeom g, uint8_t* __restrict__ pyr_prev,
-                                     uint8_t* __restrict__ pyr_curr) {
-    const int pair = blockIdx.z >> 1, which = blockIdx.z & 1;
+                                     size_t prev_row_stride, size_t curr_row_stride, bool two_sets, LkGeom g,
+                                     uint8_t* __restrict__ pyr_prev, uint8_t* __restrict__ pyr_curr) {
+    const int pair = two_sets ? blockIdx.z >> 1 : blockIdx.z, which = two_sets ? blockIdx.z & 1 : 0;
+    const size_t row_stride = which ? curr_row_stride : prev_row_stride;
     const uint8_t* src = (which ? curr : prev) + (size_t)pair * image_stride;
     uint8_t* dst = (which ? pyr_curr : pyr_prev) + (size_t)pair * g.block + g.img_off[0];
     const int S = g.stride[0], w = g.w[0], h = g.h[0];
@@ -195,9 +197,9 @@ __device__ __forceinline__ void pyr_down_block(const uint8_t* src, int SS, int x
 // mirror it; a group in the left or right border is the reversed group of the mirrored image
 // columns.  A level is taller than the window (lk_num_levels), so a border row mirrors exactly
 // one image row and every padded row is written once.
-__global__ void lk_pyr_down_kernel(LkGeom g, int level, uint8_t* __restrict__ pyr_prev,
+__global__ void lk_pyr_down_kernel(LkGeom g, int level, bool two_sets, uint8_t* __restrict__ pyr_prev,
                                    uint8_t* __restrict__ pyr_curr) {
-    const int pair = blockIdx.z >> 1, which = blockIdx.z & 1;
+    const int pair = two_sets ? blockIdx.z >> 1 : blockIdx.z, which = two_sets ? blockIdx.z & 1 : 0;
     uint8_t* base = (which ? pyr_curr : pyr_prev) + (size_t)pair * g.block;
     const uint8_t* src = base + g.img_off[level - 1];
     uint8_t* dst = base + g.img_off[level];
@@ -247,10 +249,12 @@ __global__ void lk_pyr_down_kernel(LkGeom g, int level, uint8_t* __restrict__ py
 // blockIdx.z = pair); zero in the border.  One thread writes four adjacent pixels as one
 // 16-byte store (a wave: 1 KiB of one row) from one unaligned 8-byte load of each of the three
 // source rows.
-__global__ void lk_scharr_kernel(LkGeom g, const uint8_t* __restrict__ pyr_prev,
-                                 uint32_t* __restrict__ deriv) {
+// pairs (optional): pair p reads pyramid pairs[2 p] of n_pyramids (clamped into range).
+__global__ void lk_scharr_kernel(LkGeom g, const uint8_t* __restrict__ pyr_prev, const int32_t* __restrict__ pairs,
+                                 int n_pyramids, uint32_t* __restrict__ deriv) {
     const int level = blockIdx.y, pair = blockIdx.z;
-    const uint8_t* src = pyr_prev + (size_t)pair * g.block + g.img_off[level];
+    const int from = pairs ? min(max(pairs[2 * pair], 0), n_pyramids - 1) : pair;
+    const uint8_t* src = pyr_prev + (size_t)from * g.block + g.img_off[level];
     uint32_t* dst = deriv + (size_t)pair * g.block + g.img_off[level];
     const int S = g.stride[level], w = g.w[level], h = g.h[level];
     const int per_row = S / 4, total = per_row * (h + 2 * g.bh);
@@ -305,6 +309,8 @@ struct LkArgs {
     const uint8_t* pyr_prev;
     const uint8_t* pyr_curr;
     const uint32_t* deriv;
+    const int32_t* pairs;   // optional: pair p tracks from pyramid pairs[2p] to pyramid pairs[2p+1]
+    int n_pyramids;         // of pyr_prev == pyr_curr (pair list in use)
     const float2* prev_pts;
     int n;        // points per pair
     int n_pairs;
@@ -663,8 +669,13 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
     const bool pt_live = local_raw < a.n;
     const int pt = pair * a.n + (pt_live ? local_raw : a.n - 1);  // surplus rows repeat the last point
     const LkGeom& g = a.g;
-    const uint8_t* pyrI = a.pyr_prev + (size_t)pair * g.block;
-    const uint8_t* pyrJ = a.pyr_curr + (size_t)pair * g.block;
+    int from = pair, to = pair;
+    if (a.pairs) {   // wave-uniform; out-of-range entries are clamped rather than followed
+        from = min(max(a.pairs[2 * pair], 0), a.n_pyramids - 1);
+        to = min(max(a.pairs[2 * pair + 1], 0), a.n_pyramids - 1);
+    }
+    const uint8_t* pyrI = a.pyr_prev + (size_t)from * g.block;
+    const uint8_t* pyrJ = a.pyr_curr + (size_t)to * g.block;
     const uint32_t* pyrD = a.deriv + (size_t)pair * g.block;
 
     // slot geometry of this lane: (window row << 8 | first window column) per slot
@@ -704,15 +715,14 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
     // lower row) and two more by lane 15 alone.
     auto load_rows8 = [&](const uint8_t* base, unsigned o0, const unsigned (&soff)[SPL], int S, uint2 (&up)[SPL],
                           uint2 (&lo)[SPL]) {
-        if (!VERT) {
+        if constexpr (!VERT) {
 #pragma unroll
             for (int s = 0; s < SPL; ++s) {
                 up[s] = load_u8x8(base + (o0 + soff[s]));
                 lo[s] = load_u8x8(base + (o0 + soff[s] + (unsigned)S));
             }
             return;
-        }
-        if (FLY) {   // lane 15: slots 0, 2, 3 side by side; its slot 1 holds rows of no meaning
+        } else if constexpr (FLY) {   // lane 15: slots 0, 2, 3 side by side; its slot 1 holds rows of no meaning
             uint2 x2 = make_uint2(0, 0), x3 = x2;
             if (own_rows) {
                 x2 = load_u8x8(base + (o0 + soff[2]));
@@ -724,21 +734,21 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
             up[1] = lo[0];
             up[2] = own_rows ? x2 : lo[1];
             up[3] = own_rows ? x3 : lo[2];
-            return;
-        }
-        // lane 15's own loads first, into registers of their own: all seven loads are then in
-        // flight together (a load that overwrote a copy of lo[] would have to wait for it)
-        uint2 x1 = make_uint2(0, 0), x2 = x1;
-        if (own_rows) {
-            x1 = load_u8x8(base + (o0 + soff[1]));
-            x2 = load_u8x8(base + (o0 + soff[2]));
-        }
-        up[0] = load_u8x8(base + (o0 + soff[0]));
+        } else {
+            // lane 15's own loads first, into registers of their own: all seven loads are then in
+            // flight together (a load that overwrote a copy of lo[] would have to wait for it)
+            uint2 x1 = make_uint2(0, 0), x2 = x1;
+            if (own_rows) {
+                x1 = load_u8x8(base + (o0 + soff[1]));
+                x2 = load_u8x8(base + (o0 + soff[2]));
+            }
+            up[0] = load_u8x8(base + (o0 + soff[0]));
 #pragma unroll
-        for (int s = 0; s < SPL; ++s) lo[s] = load_u8x8(base + (o0 + soff[s] + (unsigned)S));
-        up[1] = own_rows ? x1 : lo[0];
-        up[2] = own_rows ? x2 : lo[1];
-        up[3] = lo[2];
+            for (int s = 0; s < SPL; ++s) lo[s] = load_u8x8(base + (o0 + soff[s] + (unsigned)S));
+            up[1] = own_rows ? x1 : lo[0];
+            up[2] = own_rows ? x2 : lo[1];
+            up[3] = lo[2];
+        }
     };
 
     const float2 p0 = a.prev_pts[pt];
@@ -949,7 +959,7 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
                 pA[2] = mad24(w.y6, w.y6, sdot2(w.y45, w.y45, sdot2(w.y23, w.y23, sdot2(w.y01, w.y01, pA[2]))));
             }
         } else {
-        if (VERT) {
+        if constexpr (VERT) {
             load_rows8(I, obase, soff, S, iu, il);
             auto load_d = [&](unsigned o, uint4 (&r)[2]) { __builtin_memcpy(r, D + o, 32); };
             // an invalid slot reads the zero border at the start of the padded level
@@ -1337,86 +1347,73 @@ int sfm_filter_tracked_dev(sfm_ctx* ctx, const float* d_prev_pts, const float* d
     return SFM_OK;
 }
 
-size_t sfm_pyrlk_workspace(int n_pairs, int width, int height, int win_w, int win_h,
-                           int max_level) {
-    if (n_pairs <= 0 || width <= 0 || height <= 0 || win_w <= 2 || win_h <= 2 || max_level < 0)
-        return 0;
-    LkGeom g;
-    make_geom(width, height, win_w, win_h, max_level, &g);
-    Carver c(nullptr);
-    LkBuffers b;
-    return lk_carve(c, g, n_pairs, lk_needs_deriv_image(win_w, win_h), &b);
-}
+}  // extern "C"
 
-int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_curr, int n_pairs,
-                        size_t image_stride, int width, int height, size_t stride,
-                        const float* d_prev_pts, int n, int win_w, int win_h, int max_level,
-                        int crit_type, int max_count, double epsilon, double min_eig_threshold,
-                        float max_error, float* d_curr_pts, uint8_t* d_status, float* d_err) {
-    SFM_RETURN_IF(check_lk_args(ctx, width, height, stride, n, win_w, win_h, max_level));
-    if (n_pairs < 0) return set_error(ctx, SFM_E_INVALID, "negative pair count");
-    if (n == 0 || n_pairs == 0) return SFM_OK;
-    if (!d_prev || !d_curr || !d_prev_pts || !d_curr_pts || !d_status)
-        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
-    if (n_pairs > 1 && image_stride < (size_t)height * stride)
-        return set_error(ctx, SFM_E_INVALID, "image stride smaller than an image");
-    if ((long long)n * n_pairs > 0x7fffffffLL / 4 || 2 * (long long)n_pairs > 65535)
-        return set_error(ctx, SFM_E_INVALID, "batch too large");
-    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+namespace {
 
-    // SparsePyrLKOpticalFlowImpl::calc: criteria clamping
-    if ((crit_type & SFM_TERM_COUNT) == 0)
-        max_count = 30;
-    else
-        max_count = max_count < 0 ? 0 : (max_count > 100 ? 100 : max_count);
-    if ((crit_type & SFM_TERM_EPS) == 0)
-        epsilon = 0.01;
-    else
-        epsilon = epsilon < 0. ? 0. : (epsilon > 10. ? 10. : epsilon);
-    epsilon *= epsilon;
-
-    LkArgs a{};
-    make_geom(width, height, win_w, win_h, max_level, &a.g);
-    const LkGeom& g = a.g;
-    Carver sz(nullptr);
-    LkBuffers bufs;
-    const bool deriv_image = lk_needs_deriv_image(win_w, win_h);
-    const size_t need = lk_carve(sz, g, n_pairs, deriv_image, &bufs);
-    void* ws;
-    SFM_RETURN_IF(workspace(ctx, need, &ws));
-    Carver c(ws);
-    lk_carve(c, g, n_pairs, deriv_image, &bufs);
-
+// Pads level 0 and builds the other levels for `n` images per set (one set, or a previous and a
+// next set of n images each) into pyramid blocks of g.block bytes.
+int lk_build_levels(sfm_ctx* ctx, const LkGeom& g, const uint8_t* d_prev, const uint8_t* d_curr, int n,
+                    size_t image_stride, size_t prev_stride, size_t curr_stride, bool two_sets, uint8_t* pyr_prev,
+                    uint8_t* pyr_curr) {
     const dim3 blk(256);
+    const unsigned nz = (unsigned)(two_sets ? 2 * n : n);
     {
         const int S = g.stride[0];
-        const dim3 grid(((S / 16) * (g.h[0] + 2 * g.bh) + 255) / 256, 1, 2 * n_pairs);
+        const dim3 grid(((S / 16) * (g.h[0] + 2 * g.bh) + 255) / 256, 1, nz);
         KernelTimer timer(ctx, KID_LK_PAD_LEVEL0);
-        hipLaunchKernelGGL(lk_pad_level0_kernel, grid, blk, 0, ctx->stream, d_prev, d_curr,
-                           image_stride, stride, g, bufs.pyr_prev, bufs.pyr_curr);
+        hipLaunchKernelGGL(lk_pad_level0_kernel, grid, blk, 0, ctx->stream, d_prev, d_curr, image_stride,
+                           prev_stride, curr_stride, two_sets, g, pyr_prev, pyr_curr);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
     for (int l = 1; l <= g.levels; ++l) {
         const int S = g.stride[l];
-        const dim3 grid(((S / 4) * ((g.h[l] + kPyrRows - 1) / kPyrRows) + 255) / 256, 1, 2 * n_pairs);
+        const dim3 grid(((S / 4) * ((g.h[l] + kPyrRows - 1) / kPyrRows) + 255) / 256, 1, nz);
         KernelTimer timer(ctx, KID_LK_PYR_DOWN);
-        hipLaunchKernelGGL(lk_pyr_down_kernel, grid, blk, 0, ctx->stream, g, l, bufs.pyr_prev,
-                           bufs.pyr_curr);
+        hipLaunchKernelGGL(lk_pyr_down_kernel, grid, blk, 0, ctx->stream, g, l, two_sets, pyr_prev, pyr_curr);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
+    return SFM_OK;
+}
+
+// SparsePyrLKOpticalFlowImpl::calc: criteria clamping
+void lk_clamp_criteria(int crit_type, int* max_count, double* epsilon) {
+    if ((crit_type & SFM_TERM_COUNT) == 0)
+        *max_count = 30;
+    else
+        *max_count = *max_count < 0 ? 0 : (*max_count > 100 ? 100 : *max_count);
+    if ((crit_type & SFM_TERM_EPS) == 0)
+        *epsilon = 0.01;
+    else
+        *epsilon = *epsilon < 0. ? 0. : (*epsilon > 10. ? 10. : *epsilon);
+    *epsilon *= *epsilon;
+}
+
+// The derivative image (window sizes whose tracker reads one) and the tracker launch over
+// pyramids that exist: pair p tracks from block p of pyr_prev to block p of pyr_curr, or, with a
+// pair list, from block d_pairs[2p] to block d_pairs[2p+1] of the one array both pointers name.
+int lk_track_pyramids(sfm_ctx* ctx, const LkGeom& g, const uint8_t* pyr_prev, const uint8_t* pyr_curr,
+                      const int32_t* d_pairs, int n_pyramids, uint32_t* deriv, int n_pairs, const float* d_prev_pts,
+                      int n, int win_w, int win_h, int max_count, double epsilon_sq, double min_eig_threshold,
+                      float max_error, float* d_curr_pts, uint8_t* d_status, float* d_err) {
+    const dim3 blk(256);
+    const bool deriv_image = deriv != nullptr;
     if (deriv_image) {
         const int S = g.stride[0];
         // four groups per thread at level 0: workgroups that find nothing to do at the smaller
         // levels are then a small part of the launch
         const dim3 grid(((S / 4) * (g.h[0] + 2 * g.bh) + 1023) / 1024, g.levels + 1, n_pairs);
         KernelTimer timer(ctx, KID_LK_SCHARR);
-        hipLaunchKernelGGL(lk_scharr_kernel, grid, blk, 0, ctx->stream, g, bufs.pyr_prev, bufs.deriv);
+        hipLaunchKernelGGL(lk_scharr_kernel, grid, blk, 0, ctx->stream, g, pyr_prev, d_pairs, n_pyramids, deriv);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
-
-    a.pyr_prev = bufs.pyr_prev;
-    a.pyr_curr = bufs.pyr_curr;
-    a.deriv = bufs.deriv;
+    LkArgs a{};
+    a.g = g;
+    a.pyr_prev = pyr_prev;
+    a.pyr_curr = pyr_curr;
+    a.deriv = deriv;
+    a.pairs = d_pairs;
+    a.n_pyramids = n_pyramids;
     a.prev_pts = reinterpret_cast<const float2*>(d_prev_pts);
     a.n = n;
     a.n_pairs = n_pairs;
@@ -1425,7 +1422,7 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     a.segs = (win_w + kPxPerSlot - 1) / kPxPerSlot;
     a.slots = a.segs * win_h;
     a.max_count = max_count;
-    a.epsilon = epsilon;
+    a.epsilon = epsilon_sq;
     a.min_eig = (float)min_eig_threshold;
     a.max_error = max_error;
     for (int l = 0; l <= g.levels; ++l) a.lscale[l] = (float)(1. / (1 << l));
@@ -1437,13 +1434,13 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
         const char* e = getenv("SFM_LK_LANES");
         return e && atoi(e) == 8;
     }();
-    if (a.slots <= 64 && a.slots > 56 && eight_lanes && win_w % kPxPerSlot == 0) {
+    if (a.slots <= 64 && a.slots > 56 && eight_lanes && win_w % kPxPerSlot == 0 && deriv_image) {
         const long waves = (long)n_pairs * ((n + 7) / 8);
         const dim3 grid((unsigned)((((waves + 3) / 4 + 7) / 8) * 8));
         hipLaunchKernelGGL((lk_track_kernel<8, 8, true>), grid, blk, 0, ctx->stream, a);
     } else if (a.slots <= 64) {
-        // four points per wave, 16 lanes each
-        // four waves per workgroup, four points per wave; a multiple of 8 workgroups (see the kernel)
+        // four waves per workgroup, four points per wave (16 lanes each); a multiple of 8
+        // workgroups (see the kernel)
         const long waves = (long)n_pairs * ((n + 3) / 4);
         const dim3 grid((unsigned)((((waves + 3) / 4 + 7) / 8) * 8));
         const bool full = win_w % kPxPerSlot == 0;
@@ -1481,11 +1478,128 @@ int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_cu
     return SFM_OK;
 }
 
-int sfm_pyrlk(sfm_ctx* ctx, const uint8_t* prev, const uint8_t* curr, int width, int height,
-              size_t stride, const float* prev_pts, int n, int win_w, int win_h, int max_level,
-              int crit_type, int max_count, double epsilon, double min_eig_threshold,
-              float max_error, float* curr_pts, uint8_t* status, float* err) {
+}  // namespace
+
+extern "C" {
+
+size_t sfm_pyrlk_workspace(int n_pairs, int width, int height, int win_w, int win_h,
+                           int max_level) {
+    if (n_pairs <= 0 || width <= 0 || height <= 0 || win_w <= 2 || win_h <= 2 || max_level < 0)
+        return 0;
+    LkGeom g;
+    make_geom(width, height, win_w, win_h, max_level, &g);
+    Carver c(nullptr);
+    LkBuffers b;
+    return lk_carve(c, g, n_pairs, lk_needs_deriv_image(win_w, win_h), &b);
+}
+
+int sfm_pyrlk_batch_dev(sfm_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_curr, int n_pairs,
+                        size_t image_stride, int width, int height, size_t stride,
+                        const float* d_prev_pts, int n, int win_w, int win_h, int max_level,
+                        int crit_type, int max_count, double epsilon, double min_eig_threshold,
+                        float max_error, float* d_curr_pts, uint8_t* d_status, float* d_err) {
     SFM_RETURN_IF(check_lk_args(ctx, width, height, stride, n, win_w, win_h, max_level));
+    if (n_pairs < 0) return set_error(ctx, SFM_E_INVALID, "negative pair count");
+    if (n == 0 || n_pairs == 0) return SFM_OK;
+    if (!d_prev || !d_curr || !d_prev_pts || !d_curr_pts || !d_status)
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (n_pairs > 1 && image_stride < (size_t)height * stride)
+        return set_error(ctx, SFM_E_INVALID, "image stride smaller than an image");
+    if ((long long)n * n_pairs > 0x7fffffffLL / 4 || 2 * (long long)n_pairs > 65535)
+        return set_error(ctx, SFM_E_INVALID, "batch too large");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    lk_clamp_criteria(crit_type, &max_count, &epsilon);
+
+    LkGeom g;
+    make_geom(width, height, win_w, win_h, max_level, &g);
+    Carver sz(nullptr);
+    LkBuffers bufs;
+    const bool deriv_image = lk_needs_deriv_image(win_w, win_h);
+    const size_t need = lk_carve(sz, g, n_pairs, deriv_image, &bufs);
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, need, &ws));
+    Carver c(ws);
+    lk_carve(c, g, n_pairs, deriv_image, &bufs);
+    SFM_RETURN_IF(lk_build_levels(ctx, g, d_prev, d_curr, n_pairs, image_stride, stride, stride, true,
+                                  bufs.pyr_prev, bufs.pyr_curr));
+    return lk_track_pyramids(ctx, g, bufs.pyr_prev, bufs.pyr_curr, nullptr, n_pairs, bufs.deriv, n_pairs, d_prev_pts,
+                             n, win_w, win_h, max_count, epsilon, min_eig_threshold, max_error, d_curr_pts, d_status,
+                             d_err);
+}
+
+size_t sfm_lk_pyramid_bytes(int width, int height, int win_w, int win_h, int max_level) {
+    if (width <= 0 || height <= 0 || win_w <= 2 || win_h <= 2 || max_level < 0 || win_w > 41 || win_h > 41) return 0;
+    LkGeom g;
+    make_geom(width, height, win_w, win_h, max_level, &g);
+    return g.block;
+}
+
+int sfm_lk_build_pyramids_dev(sfm_ctx* ctx, const uint8_t* d_frames, int n_frames, size_t image_stride, int width,
+                              int height, size_t stride, int win_w, int win_h, int max_level, uint8_t* d_pyramids) {
+    SFM_RETURN_IF(check_lk_args(ctx, width, height, stride, 0, win_w, win_h, max_level));
+    if (n_frames < 0) return set_error(ctx, SFM_E_INVALID, "negative frame count");
+    if (n_frames == 0) return SFM_OK;
+    if (!d_frames || !d_pyramids) return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (n_frames > 1 && image_stride < (size_t)height * stride)
+        return set_error(ctx, SFM_E_INVALID, "image stride smaller than an image");
+    if (n_frames > 65535) return set_error(ctx, SFM_E_INVALID, "batch too large");
+    if (reinterpret_cast<uintptr_t>(d_pyramids) & 15)
+        return set_error(ctx, SFM_E_INVALID, "the pyramid array must be 16-byte aligned");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    LkGeom g;
+    make_geom(width, height, win_w, win_h, max_level, &g);
+    return lk_build_levels(ctx, g, d_frames, d_frames, n_frames, image_stride, stride, stride, false, d_pyramids,
+                           d_pyramids);
+}
+
+size_t sfm_pyrlk_pyramids_workspace(int n_pairs, int width, int height, int win_w, int win_h, int max_level) {
+    if (n_pairs <= 0 || width <= 0 || height <= 0 || win_w <= 2 || win_h <= 2 || max_level < 0) return 0;
+    if (!lk_needs_deriv_image(win_w, win_h)) return 0;
+    LkGeom g;
+    make_geom(width, height, win_w, win_h, max_level, &g);
+    Carver c(nullptr);
+    c.take<uint32_t>(g.block * n_pairs);
+    return c.total();
+}
+
+int sfm_pyrlk_pyramids_dev(sfm_ctx* ctx, const uint8_t* d_pyramids, int n_pyramids, const int32_t* d_pairs,
+                           int n_pairs, int width, int height, const float* d_prev_pts, int n, int win_w, int win_h,
+                           int max_level, int crit_type, int max_count, double epsilon, double min_eig_threshold,
+                           float max_error, float* d_curr_pts, uint8_t* d_status, float* d_err) {
+    SFM_RETURN_IF(check_lk_args(ctx, width, height, (size_t)width, n, win_w, win_h, max_level));
+    if (n_pairs < 0 || n_pyramids < 0) return set_error(ctx, SFM_E_INVALID, "negative count");
+    if (n == 0 || n_pairs == 0) return SFM_OK;
+    if (!d_pyramids || !d_pairs || !d_prev_pts || !d_curr_pts || !d_status)
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (n_pyramids == 0) return set_error(ctx, SFM_E_INVALID, "pairs but no pyramids");
+    if ((long long)n * n_pairs > 0x7fffffffLL / 4 || n_pairs > 65535)
+        return set_error(ctx, SFM_E_INVALID, "batch too large");
+    if (reinterpret_cast<uintptr_t>(d_pyramids) & 15)
+        return set_error(ctx, SFM_E_INVALID, "the pyramid array must be 16-byte aligned");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    lk_clamp_criteria(crit_type, &max_count, &epsilon);
+    LkGeom g;
+    make_geom(width, height, win_w, win_h, max_level, &g);
+    uint32_t* deriv = nullptr;
+    if (lk_needs_deriv_image(win_w, win_h)) {
+        Carver sz(nullptr);
+        sz.take<uint32_t>(g.block * n_pairs);
+        void* ws;
+        SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
+        Carver c(ws);
+        deriv = c.take<uint32_t>(g.block * n_pairs);
+    }
+    return lk_track_pyramids(ctx, g, d_pyramids, d_pyramids, d_pairs, n_pyramids, deriv, n_pairs, d_prev_pts, n,
+                             win_w, win_h, max_count, epsilon, min_eig_threshold, max_error, d_curr_pts, d_status,
+                             d_err);
+}
+
+int sfm_pyrlk(sfm_ctx* ctx, const uint8_t* prev, const uint8_t* curr, int width, int height,
+              size_t prev_stride, size_t curr_stride, const float* prev_pts, int n, int win_w, int win_h,
+              int max_level, int crit_type, int max_count, double epsilon, double min_eig_threshold,
+              float max_error, float* curr_pts, uint8_t* status, float* err) {
+    SFM_RETURN_IF(check_lk_args(ctx, width, height, prev_stride, n, win_w, win_h, max_level));
+    if (curr_stride < (size_t)width) return set_error(ctx, SFM_E_INVALID, "bad image size or stride");
     if (n == 0) return SFM_OK;
     if (!prev || !curr || !prev_pts || !curr_pts || !status)
         return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
@@ -1507,8 +1621,9 @@ int sfm_pyrlk(sfm_ctx* ctx, const uint8_t* prev, const uint8_t* curr, int width,
     float* dout = c.take<float>(2 * (size_t)n);
     float* derr = c.take<float>((size_t)n);
     uint8_t* dst = c.take<uint8_t>((size_t)n);
-    SFM_RETURN_IF(upload_rows(ctx, dp, prev, stride, (size_t)width, (size_t)height));
-    SFM_RETURN_IF(upload_rows(ctx, dc, curr, stride, (size_t)width, (size_t)height));
+    // each image is gathered with its own row pitch (one may be a region of a larger image)
+    SFM_RETURN_IF(upload_rows(ctx, dp, prev, prev_stride, (size_t)width, (size_t)height));
+    SFM_RETURN_IF(upload_rows(ctx, dc, curr, curr_stride, (size_t)width, (size_t)height));
     SFM_HIP_CHECK(ctx, hipMemcpyAsync(dpts, prev_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice,
                                       ctx->stream));
     SFM_RETURN_IF(sfm_pyrlk_batch_dev(ctx, dp, dc, 1, img_bytes, width, height, (size_t)width, dpts,

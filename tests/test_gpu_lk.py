@@ -179,6 +179,69 @@ def test_pyrlk_host_region_of_interest(ctx, oracle):
         np.testing.assert_array_equal(err, oerr)
 
 
+def test_pyrlk_host_two_row_pitches(ctx, oracle):
+    """One image a region of a wider buffer, the other dense (and the other way round): calc at
+    Source Files/feature_processing.cpp:241 accepts images whose row pitches differ."""
+    h, w = 131, 177
+    p, c, pts = _pair(h, w, 41, 220)
+    wide = np.full((h, w + 29), 7, np.uint8)
+    onxt, ost, oerr = oracle.pyrlk(p, c, pts, acc_exact=True)
+    for roi_is_prev in (True, False):
+        wide[:, 11:11 + w] = p if roi_is_prev else c
+        view = wide[:, 11:11 + w]
+        assert view.strides[0] == w + 29
+        nxt, st, err = ctx.pyrlk(view, c, pts) if roi_is_prev else ctx.pyrlk(p, view, pts)
+        np.testing.assert_array_equal(st, ost)
+        np.testing.assert_array_equal(nxt, onxt)
+        np.testing.assert_array_equal(err, oerr)
+
+
+@pytest.mark.parametrize("win,max_level", [((21, 21), 3), ((15, 11), 2)])
+def test_pyrlk_on_prebuilt_pyramids(ctx, oracle, win, max_level):
+    """A sequence of frames: every frame's pyramid built once (sfm_lk_build_pyramids_dev), then
+    frame k -> k+1 for all k plus one pair backwards and one frame against itself in one call
+    (sfm_pyrlk_pyramids_dev); equal to the oracle on the frames, bit for bit."""
+    import torch
+
+    h, w, n, F = 140, 190, 260, 5
+    frames, ptss = [], []
+    p, c, pts = _pair(h, w, 300, n)
+    frames += [p, c]
+    for f in range(F - 2):
+        _, c2, _ = _pair(h, w, 301 + f, n)
+        frames.append(c2)
+    pairs = [(k, k + 1) for k in range(F - 1)] + [(3, 1), (2, 2)]
+    rng = np.random.default_rng(77)
+    for _ in pairs:
+        q = np.stack([rng.uniform(-4, w + 4, n), rng.uniform(-4, h + 4, n)], 1).astype(np.float32)
+        ptss.append(q)
+    dev = torch.device("cuda:0")
+    stride = w + 13                                   # rows further apart than the width
+    host = np.zeros((F, h, stride), np.uint8)
+    for f in range(F):
+        host[f, :, :w] = frames[f]
+    d_frames = torch.from_numpy(host).to(dev)
+    nbytes = ctx.lk_pyramid_bytes(w, h, win, max_level)
+    assert nbytes > h * w
+    d_pyr = torch.zeros(F * nbytes, dtype=torch.uint8, device=dev)
+    d_pairs = torch.tensor(pairs, dtype=torch.int32, device=dev)
+    d_pts = torch.from_numpy(np.stack(ptss)).to(dev)
+    P = len(pairs)
+    d_out = torch.zeros((P, n, 2), dtype=torch.float32, device=dev)
+    d_st = torch.zeros((P, n), dtype=torch.uint8, device=dev)
+    d_err = torch.zeros((P, n), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx.lk_build_pyramids_dev(d_frames, F, h * stride, w, h, stride, win, max_level, d_pyr)
+    ctx.pyrlk_pyramids_dev(d_pyr, F, d_pairs, P, w, h, d_pts, n, win, max_level, 3, 30, 0.01, 1e-4, 10.0,
+                           d_out, d_st, d_err)
+    ctx.synchronize()
+    for i, (a, b) in enumerate(pairs):
+        onxt, ost, oerr = oracle.pyrlk(frames[a], frames[b], ptss[i], win=win, max_level=max_level, acc_exact=True)
+        np.testing.assert_array_equal(d_st[i].cpu().numpy(), ost)
+        np.testing.assert_array_equal(d_out[i].cpu().numpy(), onxt)
+        np.testing.assert_array_equal(d_err[i].cpu().numpy(), oerr)
+
+
 @pytest.mark.parametrize("h,w,win,max_level", [
     (33, 40, (9, 9), 2),      # narrower than two borders: per-byte reflect path everywhere
     (45, 70, (21, 21), 3),    # window almost as large as the top level
