@@ -96,6 +96,8 @@ def parse():
     ap.add_argument("--sustain", type=float, default=2.0,
                     help="framepair: seconds the step is looped after the timed region for the "
                          "'sustained' rate (0: off)")
+    ap.add_argument("--no-sequence", action="store_true",
+                    help="framepair: skip the consecutive-frames figure (pyramids built once per frame)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="framepair: skip the short runs of the other configurations "
                          "(triangulation, float matching, sharded window) reported under 'other_configs'")
@@ -234,8 +236,10 @@ def lk_roofline(prof, n_pairs, iters_per_point):
             "iterations_source": "cpu_baseline leg of this run" if iters_per_point else "constant",
             "compulsory_hbm_bytes": compulsory,
             "compulsory_hbm_GBps": round(compulsory / sec / 1e9, 1),
-            "second_limit": "the CU's vector memory path: the window gathers keep it busy 62 % of the "
-                            "kernel's cycles (TA_TA_BUSY, tools/pmc_ta.sh) beside the vector ALU",
+            "second_limit": "vector issue: about 7100 vector instructions per wave of four points "
+                            "(SQ_INSTS_VALU, tools/pmc_sq.sh), most of them half-rate byte shuffles and 16-bit "
+                            "dot products that the multiply-add count does not see; the CU's vector memory "
+                            "path is busy 34 % of the kernel's cycles (TA_TA_BUSY, tools/pmc_ta.sh)",
             "traffic": None}
 
 
@@ -279,6 +283,33 @@ def lk_inputs(pairs, seed):
         currs.append(synth.to_u8(synth.affine_warp(tex, shift, ang)))
         pts.append(synth.grid_points(LK_H, LK_W, LK_POINTS, seed=seed + p, margin=15))
     return np.stack(prevs), np.stack(currs), np.stack(pts)
+
+
+def lk_sequence_frames(n_frames, seed, dev):
+    """n_frames consecutive 1280x720 frames of one textured scene under a slow camera motion
+    (0.9, -0.6 px and 0.02 degrees per frame), sampled bilinearly from the scene on the device."""
+    import torch
+
+    from sfm_amd import synth
+
+    tex = torch.from_numpy(synth.texture(LK_H, LK_W, seed=seed)).to(dev, torch.float32)
+    ys, xs = torch.meshgrid(torch.arange(LK_H, device=dev, dtype=torch.float32),
+                            torch.arange(LK_W, device=dev, dtype=torch.float32), indexing="ij")
+    cx, cy = (LK_W - 1) / 2.0, (LK_H - 1) / 2.0
+    out = torch.empty((n_frames, LK_H, LK_W), dtype=torch.uint8, device=dev)
+    for k in range(n_frames):
+        a = np.deg2rad(0.02 * k)
+        ca, sa = float(np.cos(a)), float(np.sin(a))
+        dx, dy = xs - cx - 0.9 * k, ys - cy + 0.6 * k
+        sx, sy = ca * dx + sa * dy + cx, -sa * dx + ca * dy + cy
+        x0 = sx.floor().clamp(0, LK_W - 2)
+        y0 = sy.floor().clamp(0, LK_H - 2)
+        fx, fy = (sx - x0).clamp(0, 1), (sy - y0).clamp(0, 1)
+        x0, y0 = x0.long(), y0.long()
+        v = (tex[y0, x0] * (1 - fx) * (1 - fy) + tex[y0, x0 + 1] * fx * (1 - fy) +
+             tex[y0 + 1, x0] * (1 - fx) * fy + tex[y0 + 1, x0 + 1] * fx * fy)
+        out[k] = (v * 255.0 + 0.5).clamp(0, 255).to(torch.uint8)
+    return out
 
 
 def cpu_baseline_framepair(desc, prevs, currs, pts):
@@ -410,6 +441,42 @@ def run_framepair(args, rank, world, local):
         gathered["n"] = int(gather.counts.sum().item())
     tracked = int(d_status.sum().item())
 
+    # The reference's own use: frame k -> k+1 on every iteration (app_solver.cpp:68, :366).  P + 1
+    # consecutive frames, every frame's pyramid built once and used as the next image of one pair
+    # and the previous image of the following one.  A separate figure; `value` stays the
+    # independent pairs above.
+    sequence = None
+    if not args.no_sequence:
+        d_frames = lk_sequence_frames(P + 1, seed=4242 + rank, dev=dev)
+        pyr_bytes = capi.Context.lk_pyramid_bytes(LK_W, LK_H, LK_WIN, LK_MAXLEVEL)
+        d_pyr = torch.empty((P + 1) * pyr_bytes, dtype=torch.uint8, device=dev)
+        ctx_lk.reserve(capi.Context.pyrlk_pyramids_workspace(P, LK_W, LK_H, LK_WIN, LK_MAXLEVEL))
+        d_seq_status = torch.empty((P, LK_POINTS), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+
+        def seq_step():
+            ctx.match_pairs_dev(capi.NORM_HAMMING, d_desc, P + 1, KPS * DESC_BYTES, KPS, None,
+                                DESC_BYTES, d_pairs, P, 0.5, d_matches, cap, d_mcount)
+            ctx_lk.lk_build_pyramids_dev(d_frames, P + 1, LK_W * LK_H, LK_W, LK_H, LK_W, LK_WIN, LK_MAXLEVEL, d_pyr)
+            ctx_lk.pyrlk_pyramids_dev(d_pyr, P + 1, d_pairs, P, LK_W, LK_H, d_pts, LK_POINTS, LK_WIN, LK_MAXLEVEL,
+                                      3, LK_COUNT, LK_EPS, 1e-4, 10.0, d_out, d_seq_status, d_err)
+
+        for _ in range(args.warmup):
+            seq_step()
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            seq_step()
+        barrier_sync(world)
+        dt_seq = max_over_ranks(time.perf_counter() - t0, world, dev)
+        sequence = {"value": round(feats_step * args.steps / dt_seq, 1), "unit": "features/s",
+                    "ms_per_step": round(1e3 * dt_seq / args.steps, 4),
+                    "workload": f"{P + 1} consecutive frames, {P} pairs (k, k+1): matching as above; "
+                                f"{P + 1} pyramids built once each (sfm_lk_build_pyramids_dev) instead of "
+                                f"{2 * P}, tracking by pair list (sfm_pyrlk_pyramids_dev)",
+                    "tracked_per_step": int(d_seq_status.sum().item())}
+        del d_frames, d_pyr
+
     # roofline of the dominant kernel (by summed device time over the timed region)
     dominant = max(prof.items(), key=lambda kv: kv[1][0])[0]
     lk_ms, lk_n = prof.get("lk_track_kernel", (0.0, 0))
@@ -452,6 +519,8 @@ def run_framepair(args, rank, world, local):
     }
     if sustained is not None:
         out["sustained"] = sustained
+    if sequence is not None:
+        out["sequence"] = sequence
     if lk_n:
         out["lk_track"] = {"avg_launch_us": round(1e3 * lk_ms / lk_n, 2),
                            "points_per_s": round(P * LK_POINTS / (lk_ms / lk_n * 1e-3), 1)}

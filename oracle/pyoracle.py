@@ -125,7 +125,9 @@ def lk_num_levels(w, h, win_w, win_h, max_level):
 
 def pyrlk(prev, curr, prev_pts, win=(21, 21), max_level=3, crit_type=3, max_count=30,
           epsilon=0.01, min_eig_threshold=1e-4, max_error=10.0, acc_exact=False, threads=0,
-          return_iters=False):
+          return_iters=False, return_level_iters=False):
+    """return_level_iters: also returns an int32 array [levels + 1][n] with the iterations every
+    point ran on every pyramid level (0 where a level was skipped)."""
     prev = np.ascontiguousarray(prev, dtype=np.uint8)
     curr = np.ascontiguousarray(curr, dtype=np.uint8)
     assert prev.shape == curr.shape and prev.ndim == 2
@@ -136,14 +138,32 @@ def pyrlk(prev, curr, prev_pts, win=(21, 21), max_level=3, crit_type=3, max_coun
     status = np.zeros(n, np.uint8)
     err = np.zeros(n, np.float32)
     iters = C.c_int64(0)
+    level_iters = None
+    if return_level_iters:
+        levels = lk_num_levels(w, h, win[0], win[1], max_level)
+        level_iters = np.zeros((levels + 1, max(n, 1)), np.int32)
+        lib().orc_lk_set_iter_buffer(_p(level_iters))
+    try:
+        _orc_pyrlk(prev, curr, w, h, pts, n, win, max_level, crit_type, max_count, epsilon, min_eig_threshold,
+                   max_error, out, status, err, acc_exact, threads, iters)
+    finally:
+        if return_level_iters:
+            lib().orc_lk_set_iter_buffer(None)
+    res = (out, status, err)
+    if return_iters:
+        res += (iters.value,)
+    if return_level_iters:
+        res += (level_iters[:, :n],)
+    return res
+
+
+def _orc_pyrlk(prev, curr, w, h, pts, n, win, max_level, crit_type, max_count, epsilon, min_eig_threshold,
+               max_error, out, status, err, acc_exact, threads, iters):
     lib().orc_pyrlk(_p(prev), _p(curr), C.c_int(w), C.c_int(h), C.c_size_t(prev.strides[0]),
                     _p(pts), C.c_int(n), C.c_int(win[0]), C.c_int(win[1]), C.c_int(max_level),
                     C.c_int(crit_type), C.c_int(max_count), C.c_double(epsilon),
                     C.c_double(min_eig_threshold), C.c_float(max_error), _p(out), _p(status),
                     _p(err), C.c_int(1 if acc_exact else 0), C.c_int(threads), C.byref(iters))
-    if return_iters:
-        return out, status, err, iters.value
-    return out, status, err
 
 
 def triangulate(K, prev_pose, curr_pose, R, t, prev_pts, curr_pts, bgr=None, min_dist=1e-4,

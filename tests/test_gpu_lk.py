@@ -75,15 +75,35 @@ def test_pyrlk_vs_oracle(ctx, oracle, win, max_level, crit):
     np.testing.assert_array_equal(nxt, onxt)
     np.testing.assert_array_equal(err, oerr)
     assert st.sum() > 0.5 * n or win[0] <= 3
-    fnxt, fst, ferr = oracle.pyrlk(prev, curr, pts, acc_exact=False, **kw)
-    both = st.astype(bool) & fst.astype(bool)
-    # a point whose status differs between accumulator types sits on a threshold
-    assert (st != fst).mean() < 0.01
-    diff = np.abs(nxt[both] - fnxt[both]).max(axis=1)
-    # points that stop on different iterations under the two accumulators differ by up to the
-    # termination epsilon; they are rare, everything else agrees within the tolerance
-    assert (diff < TOL_PX).mean() > 0.995
-    assert np.median(diff) < 1e-5
+    _assert_float_accumulator_band(oracle, prev, curr, pts, nxt, st, kw)
+
+
+BAND_MAX_FRACTION = 0.01   # measured: 0 .. 0.34 % of the points on the shapes of this file
+
+
+def _assert_float_accumulator_band(oracle, prev, curr, pts, nxt, st, kw):
+    """The GPU result (bit-identical to the oracle's exact-accumulator mode) against the oracle
+    with OpenCV's float accumulators, point by point.  Points whose two runs execute the same
+    number of iterations on every pyramid level must agree within TOL_PX, all of them, status
+    included.  The others (the exclusion band: a stop test decided differently under the two
+    roundings) are few, and still agree within the termination epsilon."""
+    eps = kw.get("epsilon", 0.01) if kw.get("crit_type", 3) & 2 else 0.01
+    eps = min(max(eps, 0.0), 10.0)
+    e = oracle.pyrlk(prev, curr, pts, acc_exact=True, return_level_iters=True, **kw)
+    f = oracle.pyrlk(prev, curr, pts, acc_exact=False, return_level_iters=True, **kw)
+    np.testing.assert_array_equal(nxt, e[0])
+    same = (e[3] == f[3]).all(axis=0)
+    # same iterations everywhere: same status, positions within the tolerance
+    np.testing.assert_array_equal(st[same], f[1][same])
+    tracked = same & st.astype(bool)
+    if tracked.any():
+        assert np.abs(nxt[tracked] - f[0][tracked]).max() < TOL_PX
+    band = ~same
+    assert band.mean() <= BAND_MAX_FRACTION
+    both = band & st.astype(bool) & f[1].astype(bool)
+    if both.any():
+        assert np.abs(nxt[both] - f[0][both]).max() <= max(eps, TOL_PX)
+    return band.mean()
 
 
 def test_pyrlk_c2_shape_and_truth(ctx, oracle):
@@ -101,6 +121,8 @@ def test_pyrlk_c2_shape_and_truth(ctx, oracle):
     ok = st.astype(bool)
     assert ok.mean() > 0.95
     assert np.median(np.abs(nxt[ok] - truth[ok])) < 0.05
+    # the stated tolerance at the size the metric is quoted on (measured band: 0.32 % of 5000)
+    _assert_float_accumulator_band(oracle, prev, curr, pts, nxt, st, {})
 
 
 def test_pyrlk_identical_images(ctx, oracle):

@@ -11,15 +11,16 @@ from oracle import pyoracle  # noqa: E402
 from sfm_amd import capi, synth  # noqa: E402
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else [str(a) for a in argv]
+    n_cases = int(argv[0]) if len(argv) > 0 else 120
     rng = np.random.default_rng(99)
     ctx = capi.Context(0)
     bad = 0
     for case in range(n_cases):
         h = int(rng.integers(3, 300))
         w = int(rng.integers(3, 400))
-        if len(sys.argv) > 2 and sys.argv[2] == "big":   # up to full-HD frames
+        if len(argv) > 1 and argv[1] == "big":   # up to full-HD frames
             h, w = int(rng.integers(300, 1100)), int(rng.integers(400, 2000))
         kind = int(rng.integers(0, 4))
         if kind == 0 and min(h, w) >= 16:
@@ -50,4 +51,5 @@ def main():
     return 1 if bad else 0
 
 
-sys.exit(main())
+if __name__ == "__main__":
+    sys.exit(main())

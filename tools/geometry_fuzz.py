@@ -13,11 +13,13 @@ from oracle import pyoracle  # noqa: E402
 from sfm_amd import capi, synth  # noqa: E402
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else [str(a) for a in argv]
+    n_cases = int(argv[0]) if len(argv) > 0 else 100
     rng = np.random.default_rng(5)
     ctx = capi.Context(0)
     same_f = same_e = 0
+    strict_bad = 0      # differing masks from 15 points on (RANSAC, or an LMedS median outside the sample)
     for case in range(n_cases):
         n = int(rng.choice([8, 15, 40, 200, 1000, 5000]))
         seed = int(rng.integers(0, 10 ** 6))
@@ -37,6 +39,10 @@ def main():
         ok_e = np.array_equal(emask, oemask)
         same_e += ok_e
         if not (ok_f and ok_e):
+            # 8-point sets run LMedS on 7- / 5-point samples: the median of eight residuals is the
+            # residual of a sample point, a rounding residue, so the winner is decided below 1e-15
+            strict_bad += n >= 15
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             np.savez(os.path.join(ROOT, "gpurun_out", f"geom_case{case}.npz"), p1=p1, p2=p2, K=s["K"], F=F, oF=oF,
                      mask=mask, omask=omask, E=E, oE=oE, emask=emask, oemask=oemask, method=method, thresh=thresh)
             with np.printoptions(precision=6, linewidth=200):
@@ -47,8 +53,11 @@ def main():
             print(f"case {case}: n={n} seed={seed} method={method} thresh={thresh}: fundamental mask "
                   f"{'same' if ok_f else f'differs in {int((mask != omask).sum())}'}, essential mask "
                   f"{'same' if ok_e else f'differs in {int((emask != oemask).sum())}'}", flush=True)
-    print(f"fundamental: {same_f} of {n_cases} masks identical; essential: {same_e} of {n_cases}")
-    return 0
+    print(f"fundamental: {same_f} of {n_cases} masks identical; essential: {same_e} of {n_cases}; "
+          f"{strict_bad} differing cases with 15 or more points")
+    ctx.close()
+    return 1 if strict_bad else 0
 
 
-sys.exit(main())
+if __name__ == "__main__":
+    sys.exit(main())

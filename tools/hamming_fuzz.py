@@ -11,9 +11,10 @@ from oracle import pyoracle  # noqa: E402
 from sfm_amd import capi  # noqa: E402
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    big = len(sys.argv) > 2 and sys.argv[2] == "big"   # row counts around and above one 8192-row train range
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else [str(a) for a in argv]
+    n_cases = int(argv[0]) if len(argv) > 0 else 200
+    big = len(argv) > 1 and argv[1] == "big"   # row counts around and above one 8192-row train range
     rng = np.random.default_rng(77)
     ctx = capi.Context(0)
     bad = 0
@@ -55,4 +56,5 @@ def main():
     return 1 if bad else 0
 
 
-sys.exit(main())
+if __name__ == "__main__":
+    sys.exit(main())

@@ -11,9 +11,10 @@ from oracle import pyoracle  # noqa: E402
 from sfm_amd import capi  # noqa: E402
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-    big = len(sys.argv) > 2 and sys.argv[2] == "big"   # train sets around and above 8192 rows
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else [str(a) for a in argv]
+    n_cases = int(argv[0]) if len(argv) > 0 else 150
+    big = len(argv) > 1 and argv[1] == "big"   # train sets around and above 8192 rows
     rng = np.random.default_rng(2026)
     ctx = capi.Context(0)
     bad = 0
@@ -66,4 +67,5 @@ def main():
     return 1 if bad else 0
 
 
-sys.exit(main())
+if __name__ == "__main__":
+    sys.exit(main())

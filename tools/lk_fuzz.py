@@ -12,17 +12,18 @@ from oracle import pyoracle  # noqa: E402
 from sfm_amd import capi, synth  # noqa: E402
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-    fixed_win = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # e.g. 21: every case with a 21 x 21 window
-    batch = len(sys.argv) > 3 and sys.argv[3] == "batch"       # 2-6 image pairs per call (sfm_pyrlk_batch_dev)
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else [str(a) for a in argv]
+    n_cases = int(argv[0]) if len(argv) > 0 else 120
+    fixed_win = int(argv[1]) if len(argv) > 1 else 0   # e.g. 21: every case with a 21 x 21 window
+    batch = len(argv) > 2 and argv[2] == "batch"       # 2-6 image pairs per call (sfm_pyrlk_batch_dev)
     rng = np.random.default_rng(4242)
     ctx = capi.Context(0)
     bad = 0
     for case in range(n_cases):
         h = int(rng.integers(24, 260))
         w = int(rng.integers(24, 330))
-        big = len(sys.argv) > 3 and sys.argv[3] == "big"          # frames up to full HD, thousands of points
+        big = len(argv) > 2 and argv[2] == "big"          # frames up to full HD, thousands of points
         if big:
             h, w = int(rng.integers(400, 1100)), int(rng.integers(500, 2000))
         prev, curr = synth.lk_pair(h, w, seed=int(rng.integers(0, 10 ** 6)))
@@ -93,4 +94,5 @@ def main():
     return 1 if bad else 0
 
 
-sys.exit(main())
+if __name__ == "__main__":
+    sys.exit(main())

@@ -17,8 +17,9 @@ from oracle import pyoracle  # noqa: E402
 from sfm_amd import capi  # noqa: E402
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else [str(a) for a in argv]
+    n_cases = int(argv[0]) if len(argv) > 0 else 150
     rng = np.random.default_rng(9090)
     dev = torch.device("cuda:0")
     ctx = capi.Context(0)
@@ -110,8 +111,8 @@ def main():
                   f"matches={int(mc.sum())})", flush=True)
     print(f"{n_cases - bad} of {n_cases} cases agree")
     ctx.close()
-    sys.exit(1 if bad else 0)
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

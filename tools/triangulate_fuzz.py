@@ -28,9 +28,10 @@ def rotation(rng, max_deg):
     return np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    only = int(sys.argv[2]) if len(sys.argv) > 2 else -1   # one case, with its worst points printed
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else [str(a) for a in argv]
+    n_cases = int(argv[0]) if len(argv) > 0 else 200
+    only = int(argv[1]) if len(argv) > 1 else -1   # one case, with its worst points printed
     rng = np.random.default_rng(31337)
     ctx = capi.Context(0)
     bad = 0
@@ -108,8 +109,8 @@ def main():
     print(f"{n_cases - bad} of {n_cases} cases agree; largest relative difference {worst:.3e}; "
           f"{above} cases above 1e-9")
     ctx.close()
-    sys.exit(1 if bad else 0)
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
