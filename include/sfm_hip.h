@@ -137,6 +137,20 @@ int sfm_robust_matches(sfm_ctx* ctx, int norm, const void* prev, int n_prev,
                        size_t prev_stride, const void* curr, int n_curr, size_t curr_stride,
                        int d, float ratio, sfm_dmatch* out, int* out_count);
 
+/* The ratio test and cross-check of findRobustMatches (Source Files/feature_processing.cpp:
+ * 126-129 and :159-176) on two 2-NN searches that exist on the device: d_fwd_* is
+ * sfm_knn2_dev(prev -> curr), [n_prev][2]; d_bwd_* is sfm_knn2_dev(curr -> prev), [n_curr][2].
+ * Writes up to `cap` matches in findRobustMatches' order and their number (not clipped to cap)
+ * to *d_match_count.  With sfm_knn2_dev on row slabs this splits ONE large frame pair over
+ * several GPUs: a 2-NN search is independent per query row, so every GPU searches a slab of prev
+ * rows against all of curr and a slab of curr rows against all of prev, the [rows][2] results
+ * are gathered, and this step runs on the gathered arrays (the reference re-matches the current
+ * frame against a handful of earlier views, Source Files/tracking.cpp:127-135: fewer pairs than
+ * GPUs). */
+int sfm_ratio_cross_dev(sfm_ctx* ctx, const int32_t* d_fwd_idx, const float* d_fwd_dist, int n_prev,
+                        const int32_t* d_bwd_idx, const float* d_bwd_dist, int n_curr, float ratio,
+                        sfm_dmatch* d_matches, int cap, int32_t* d_match_count);
+
 /* The same over many frame pairs in one launch sequence (the reference runs
  * it once per pair: Source Files/app_solver.cpp:404, Source Files/
  * tracking.cpp:135).  d_desc holds n_frames descriptor blocks, block f at

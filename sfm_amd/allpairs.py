@@ -9,6 +9,16 @@ per GPU, torch.distributed with the RCCL backend over xGMI; gloo on CPU for the
 tests).  There is no collective on the data path; the only exchange is the
 final all-gather of the match lists, after which every rank holds every pair's
 matches in pair order, independent of the number of ranks.
+
+Two more pieces for the same setting.  `replicate_frames`: every rank holds the descriptors
+of the frames f with f % world == rank (it produced or received those) and one all-gather
+gives every rank the whole stack -- the one sizeable payload of the configuration.  And the
+second partition, for windows with fewer pairs than ranks (the reference's own window is a
+handful of earlier views against the current frame): `match_pair_slabs` splits ONE pair by
+query rows -- rank r searches its slab of prev rows against all of curr and its slab of curr
+rows against all of prev, the [rows][2] neighbour arrays are all-gathered, and the ratio test
+and cross-check run replicated on the gathered arrays.  `match_all_pairs` takes that route by
+itself when there are fewer pairs than ranks and a slab matcher was given.
 """
 import numpy as np
 import torch
@@ -63,7 +73,8 @@ class HipPairMatcher:
 
     def __call__(self, pairs_np):
         """Returns (counts [P] int32 tensor, matches [sum(counts), 3] int16 tensor holding
-        uint16 (q, t, distance) records)."""
+        uint16 (q, t, distance) records).  Both are views into buffers this object reuses: they
+        are valid until its next call (match_all_pairs copies what it hands on)."""
         dev = self.d_desc.device
         P = len(pairs_np)
         if P == 0:
@@ -156,7 +167,104 @@ def reassemble(all_c, all_p, width, n_pairs, world, gather):
     return counts_out, offsets, matches
 
 
-def match_all_pairs(pairs, match_fn, rank=0, world=1, group=None, always_exchange=False):
+def slab_bounds(n_rows, rank, world):
+    """Rows [lo, hi) of rank `rank` when n_rows are cut into `world` slabs of near-equal size."""
+    return (n_rows * rank) // world, (n_rows * (rank + 1)) // world
+
+
+def replicate_frames(local, n_frames, rank, world, group=None):
+    """The whole descriptor stack on every rank from per-rank shares.
+
+    local: [ceil(n_frames / world), rows, d] tensor on the group's device; slot s holds frame
+    s * world + rank (slots beyond the last frame are padding).  One all-gather (as bytes),
+    then a strided copy into frame order.  Returns (stack [n_frames, rows, d], bytes received
+    from the other ranks)."""
+    per = (n_frames + world - 1) // world
+    assert local.shape[0] == per, (local.shape, per)
+    if world == 1:
+        return local[:n_frames], 0
+    local = local.contiguous()
+    gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered.view(torch.uint8).view(-1), local.view(torch.uint8).view(-1), group=group)
+    # gathered[r, s] is frame s * world + r
+    stack = gathered.transpose(0, 1).reshape((per * world,) + tuple(local.shape[1:]))[:n_frames].contiguous()
+    return stack, (world - 1) * local.numel() * local.element_size()
+
+
+class HipSlabMatcher:
+    """The two callables `match_pair_slabs` needs, on this rank's GPU: 2-NN of a slab of query
+    rows (sfm_knn2_dev) and the replicated ratio test + cross-check (sfm_ratio_cross_dev).
+    d_desc: [frames, rows, d] descriptors, every frame with `rows` rows."""
+
+    def __init__(self, ctx, norm, d_desc, ratio):
+        if ctx.stream is None or ctx.stream != torch.cuda.current_stream(d_desc.device).cuda_stream:
+            raise ValueError("HipSlabMatcher needs a Context created on torch's current stream")
+        self.ctx, self.norm, self.d_desc, self.ratio = ctx, norm, d_desc, float(ratio)
+        self.rows, self.d = d_desc.shape[1], d_desc.shape[2]
+        self.row_bytes = d_desc.stride(1) * d_desc.element_size()
+
+    def n_rows(self, frame):
+        return self.rows
+
+    def knn_slab(self, q_frame, t_frame, lo, hi):
+        dev = self.d_desc.device
+        idx = torch.empty((hi - lo, 2), dtype=torch.int32, device=dev)
+        dst = torch.empty((hi - lo, 2), dtype=torch.float32, device=dev)
+        if hi > lo:
+            self.ctx.knn2_dev(self.norm, self.d_desc[q_frame, lo:hi], hi - lo, self.row_bytes, self.d_desc[t_frame],
+                              self.rows, self.row_bytes, self.d, idx, dst)
+        return idx, dst
+
+    def cross(self, idx_f, dist_f, idx_b, dist_b):
+        dev = self.d_desc.device
+        n_prev, n_curr = idx_f.shape[0], idx_b.shape[0]
+        cap = min(n_prev, n_curr)
+        out = torch.empty((max(cap, 1), 4), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ctx.ratio_cross_dev(idx_f, dist_f, n_prev, idx_b, dist_b, n_curr, self.ratio, out, cap, cnt)
+        n = int(cnt.item())
+        m = out[:n]
+        # the exchange format of the pair partition: (prev row, curr row, distance) as 16-bit words
+        rec = torch.stack([m[:, 0], m[:, 1], m[:, 3].view(torch.float32).to(torch.int32)], 1).to(torch.int16)
+        return n, rec
+
+
+def _gather_rows(part, n_rows, rank, world, group):
+    """[n_rows, k] from every rank's slab [hi - lo, k] (slabs as slab_bounds cuts them)."""
+    if world == 1:
+        return part
+    width = max(slab_bounds(n_rows, r, world)[1] - slab_bounds(n_rows, r, world)[0] for r in range(world))
+    send = torch.zeros((max(width, 1), part.shape[1]), dtype=part.dtype, device=part.device)
+    send[: part.shape[0]] = part
+    recv = torch.empty((world,) + tuple(send.shape), dtype=part.dtype, device=part.device)
+    dist.all_gather_into_tensor(recv.view(torch.uint8).view(-1), send.view(torch.uint8).view(-1), group=group)
+    return torch.cat([recv[r, : slab_bounds(n_rows, r, world)[1] - slab_bounds(n_rows, r, world)[0]]
+                      for r in range(world)])
+
+
+def match_pair_slabs(pair, slab, rank=0, world=1, group=None):
+    """ONE frame pair split by query rows over the ranks; every rank returns the whole result.
+
+    slab: an object with n_rows(frame), knn_slab(query frame, train frame, lo, hi) -> (idx
+    [hi - lo, 2] int32, dist [hi - lo, 2] float32) and cross(idx_f, dist_f, idx_b, dist_b) ->
+    (count, matches [count, k]).  Four all-gathers of [rows][2] arrays (8 bytes per row and
+    direction each way); no reduction across ranks is needed, the two nearest rows of a query
+    are found by the rank that owns the query."""
+    a, b = int(pair[0]), int(pair[1])
+    n_prev, n_curr = slab.n_rows(a), slab.n_rows(b)
+    lo, hi = slab_bounds(n_prev, rank, world)
+    idx_f, dist_f = slab.knn_slab(a, b, lo, hi)
+    lo, hi = slab_bounds(n_curr, rank, world)
+    idx_b, dist_b = slab.knn_slab(b, a, lo, hi)
+    idx_f = _gather_rows(idx_f, n_prev, rank, world, group)
+    dist_f = _gather_rows(dist_f, n_prev, rank, world, group)
+    idx_b = _gather_rows(idx_b, n_curr, rank, world, group)
+    dist_b = _gather_rows(dist_b, n_curr, rank, world, group)
+    return slab.cross(idx_f, dist_f, idx_b, dist_b)
+
+
+def match_all_pairs(pairs, match_fn, rank=0, world=1, group=None, always_exchange=False, shard="auto",
+                    slab=None):
     """Runs match_fn on this rank's share of `pairs` and gathers every rank's result.
 
     match_fn(pairs_subset) -> (counts [p] int32, matches [sum(counts), k]) on the device the
@@ -170,16 +278,33 @@ def match_all_pairs(pairs, match_fn, rank=0, world=1, group=None, always_exchang
     then a segment copy into pair order.  With one rank there is nothing to exchange unless
     always_exchange asks for the collectives anyway (a one-rank group: how a single GPU
     exercises this path).
+
+    shard: 'pair' deals whole pairs round-robin (above); 'slab' splits every pair by query rows
+    over all ranks (`match_pair_slabs`, needs `slab`); 'auto' takes 'slab' when a slab matcher
+    is given and there are fewer pairs than ranks, 'pair' otherwise.  The result is the same.
     """
     pairs = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
     P = len(pairs)
+    if shard not in ("auto", "pair", "slab"):
+        raise ValueError("shard must be 'auto', 'pair' or 'slab'")
+    if shard == "slab" or (shard == "auto" and slab is not None and world > 1 and P < world):
+        # fewer pairs than ranks: every pair is split by query rows over all ranks
+        if slab is None:
+            raise ValueError("shard='slab' needs a slab matcher")
+        res = [match_pair_slabs(pr, slab, rank, world, group) for pr in pairs]
+        c = np.asarray([n for n, _ in res], dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(c)]).astype(np.int64)
+        if res:
+            return c, off, torch.cat([m for _, m in res])
+        return c, off, None
     mine = shard_indices(P, rank, world)
     counts, payload = match_fn(pairs[mine])
     counts = counts.to(torch.int32)
     if world == 1 and not always_exchange:
         c = counts.cpu().numpy().astype(np.int64)
         off = np.concatenate([[0], np.cumsum(c)])
-        return c, off, payload
+        # a matcher may hand out views into buffers it reuses on its next call
+        return c, off, payload.clone()
 
     dev = payload.device
     per_rank = (P + world - 1) // world

@@ -34,6 +34,7 @@ EXPORTS = [
     "sfm_l2_exhaustive_count", "sfm_knn2", "sfm_knn2_dev", "sfm_ratio_matches", "sfm_robust_matches",
     "sfm_match_pairs_dev", "sfm_match_pairs_workspace",
     "sfm_match_pairs_compact_dev", "sfm_match_pairs_compact_workspace", "sfm_gather_segments_dev",
+    "sfm_ratio_cross_dev",
     "sfm_pyrlk", "sfm_pyrlk_batch_dev", "sfm_pyrlk_workspace",
     "sfm_lk_pyramid_bytes", "sfm_lk_build_pyramids_dev", "sfm_pyrlk_pyramids_dev", "sfm_pyrlk_pyramids_workspace",
     "sfm_triangulate", "sfm_triangulate_dev", "sfm_triangulate_matches_dev",
@@ -181,6 +182,12 @@ class Context:
                                       C.c_size_t(q_stride), _ptr(d_t), C.c_int(nt),
                                       C.c_size_t(t_stride), C.c_int(d), _ptr(d_idx),
                                       _ptr(d_dist)))
+
+    def ratio_cross_dev(self, d_fwd_idx, d_fwd_dist, n_prev, d_bwd_idx, d_bwd_dist, n_curr, ratio, d_matches, cap,
+                        d_match_count):
+        self.check(lib().sfm_ratio_cross_dev(
+            self._h, _ptr(d_fwd_idx), _ptr(d_fwd_dist), C.c_int(n_prev), _ptr(d_bwd_idx), _ptr(d_bwd_dist),
+            C.c_int(n_curr), C.c_float(ratio), _ptr(d_matches), C.c_int(cap), _ptr(d_match_count)))
 
     def ratio_matches(self, norm, q, t, ratio):
         q, t = self._desc(norm, q), self._desc(norm, t)

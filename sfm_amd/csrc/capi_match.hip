@@ -7,6 +7,10 @@
 #include "sfm_internal.h"
 
 namespace sfm {
+int launch_ratio_cross_two(sfm_ctx* ctx, const int32_t* d_fwd_idx, const float* d_fwd_dist, int n_prev,
+                           const int32_t* d_bwd_idx, const float* d_bwd_dist, int n_curr, float ratio,
+                           int32_t* d_best, float* d_best_dist, sfm_dmatch* d_matches, int cap,
+                           int32_t* d_match_count);
 int launch_ratio_compact(sfm_ctx* ctx, const int32_t* d_idx, const float* d_dist, int nq, int nt,
                          float ratio, sfm_dmatch* d_out, int32_t* d_count);
 int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_stride,
@@ -245,6 +249,34 @@ int sfm_knn2(sfm_ctx* ctx, int norm, const void* q, int nq, size_t q_stride, con
     SFM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->pinned_used = 0;
     return SFM_OK;
+}
+
+int sfm_ratio_cross_dev(sfm_ctx* ctx, const int32_t* d_fwd_idx, const float* d_fwd_dist, int n_prev,
+                        const int32_t* d_bwd_idx, const float* d_bwd_dist, int n_curr, float ratio,
+                        sfm_dmatch* d_matches, int cap, int32_t* d_match_count) {
+    if (!ctx) return set_error(nullptr, SFM_E_INVALID, "ctx is NULL");
+    if (n_prev < 0 || n_curr < 0 || cap < 0) return set_error(ctx, SFM_E_INVALID, "negative count");
+    if (!d_match_count || (cap > 0 && !d_matches)) return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if ((n_prev > 0 && (!d_fwd_idx || !d_fwd_dist)) || (n_curr > 0 && (!d_bwd_idx || !d_bwd_dist)))
+        return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
+    if (n_prev >= kMaxTrainRows || n_curr >= kMaxTrainRows)
+        return set_error(ctx, SFM_E_INVALID, "a frame must have fewer than 2^18 rows");
+    SFM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (n_prev == 0 || n_curr == 0) {   // feature_processing.cpp:184: nothing to cross-check
+        SFM_HIP_CHECK(ctx, hipMemsetAsync(d_match_count, 0, sizeof(int32_t), ctx->stream));
+        return SFM_OK;
+    }
+    const size_t rows = (size_t)std::max(n_prev, n_curr);
+    Carver sz(nullptr);
+    sz.take<int32_t>(2 * rows);
+    sz.take<float>(2 * rows);
+    void* ws;
+    SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
+    Carver c(ws);
+    int32_t* best = c.take<int32_t>(2 * rows);
+    float* best_dist = c.take<float>(2 * rows);
+    return launch_ratio_cross_two(ctx, d_fwd_idx, d_fwd_dist, n_prev, d_bwd_idx, d_bwd_dist, n_curr, ratio, best,
+                                  best_dist, d_matches, cap, d_match_count);
 }
 
 int sfm_ratio_matches(sfm_ctx* ctx, int norm, const void* q, int nq, size_t q_stride, const void* t,

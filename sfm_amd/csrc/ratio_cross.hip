@@ -27,6 +27,8 @@ struct CrossArgs {
     int col_block_rows;       // > 0: direction 1 has one part per col_block_rows rows of prev
     const int32_t* knn_idx;   // [2*n_pairs][rows_max][2]
     const float* knn_dist;
+    const int32_t* knn_idx_b;   // set: one pair whose backward search is its own array [n_curr][2]
+    const float* knn_dist_b;    //      (knn_idx / knn_dist then hold the forward search [n_prev][2])
     int rows_max;
     const int32_t* counts;
     int n_prev_uniform;
@@ -52,9 +54,8 @@ __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
 __global__ __launch_bounds__(256) void merge_ratio_kernel(CrossArgs a) {
     const int problem = blockIdx.y, pair = problem >> 1, dir = problem & 1;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const int fa = a.pairs[2 * pair], fb = a.pairs[2 * pair + 1];
-    const int n_prev = a.counts ? a.counts[fa] : a.n_prev_uniform;
-    const int n_curr = a.counts ? a.counts[fb] : a.n_curr_uniform;
+    const int n_prev = a.counts ? a.counts[a.pairs[2 * pair]] : a.n_prev_uniform;
+    const int n_curr = a.counts ? a.counts[a.pairs[2 * pair + 1]] : a.n_curr_uniform;
     const int nq = dir ? n_curr : n_prev;
     const int nt = dir ? n_prev : n_curr;
     if (q >= nq) return;
@@ -78,11 +79,14 @@ __global__ __launch_bounds__(256) void merge_ratio_kernel(CrossArgs a) {
         i0 = m1 == kNoKey ? -1 : (int32_t)(m1 & mask);
         i1 = m2 == kNoKey ? -1 : (int32_t)(m2 & mask);
     } else {
-        const size_t o = ((size_t)problem * a.rows_max + q) * 2;
-        i0 = a.knn_idx[o];
-        i1 = a.knn_idx[o + 1];
-        d0 = a.knn_dist[o];
-        d1 = a.knn_dist[o + 1];
+        const bool own = a.knn_idx_b != nullptr;
+        const int32_t* ki = own && dir ? a.knn_idx_b : a.knn_idx;
+        const float* kd = own && dir ? a.knn_dist_b : a.knn_dist;
+        const size_t o = own ? (size_t)q * 2 : ((size_t)problem * a.rows_max + q) * 2;
+        i0 = ki[o];
+        i1 = ki[o + 1];
+        d0 = kd[o];
+        d1 = kd[o + 1];
     }
     // feature_processing.cpp:127, float * float, strict <
     const bool pass = nt >= 2 && i1 >= 0 && d0 < a.ratio * d1;
@@ -96,9 +100,8 @@ __global__ __launch_bounds__(kThreads) void ratio_cross_kernel(CrossArgs a) {
     __shared__ int wave_count[kThreads / 64];
     const int pair = blockIdx.x;
     const int tid = threadIdx.x;
-    const int fa = a.pairs[2 * pair], fb = a.pairs[2 * pair + 1];
-    const int n_prev = a.counts ? a.counts[fa] : a.n_prev_uniform;
-    const int n_curr = a.counts ? a.counts[fb] : a.n_curr_uniform;
+    const int n_prev = a.counts ? a.counts[a.pairs[2 * pair]] : a.n_prev_uniform;
+    const int n_curr = a.counts ? a.counts[a.pairs[2 * pair + 1]] : a.n_curr_uniform;
 
     const int32_t* fwd = a.best + (2 * (size_t)pair) * a.rows_max;
     const int32_t* bwd = fwd + a.rows_max;
@@ -393,6 +396,37 @@ int launch_compact_matches(sfm_ctx* ctx, const sfm_dmatch* d_matches, const int3
     const int slices = n_pairs >= 512 ? 1 : (n_pairs >= 64 ? 4 : 16);
     hipLaunchKernelGGL(compact_write_kernel, dim3(n_pairs, slices), dim3(256), 0, ctx->stream, d_matches,
                        d_counts, cap, d_offsets, d_out, out_cap);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+// One pair from two finished 2-NN searches (forward [n_prev][2], backward [n_curr][2]).
+// d_best / d_best_dist: scratch of 2 * max(n_prev, n_curr) entries each.
+int launch_ratio_cross_two(sfm_ctx* ctx, const int32_t* d_fwd_idx, const float* d_fwd_dist, int n_prev,
+                           const int32_t* d_bwd_idx, const float* d_bwd_dist, int n_curr, float ratio,
+                           int32_t* d_best, float* d_best_dist, sfm_dmatch* d_matches, int cap,
+                           int32_t* d_match_count) {
+    CrossArgs a{};
+    a.knn_idx = d_fwd_idx;
+    a.knn_dist = d_fwd_dist;
+    a.knn_idx_b = d_bwd_idx;
+    a.knn_dist_b = d_bwd_dist;
+    a.rows_max = n_prev > n_curr ? n_prev : n_curr;
+    a.n_prev_uniform = n_prev;
+    a.n_curr_uniform = n_curr;
+    a.ratio = ratio;
+    a.best = d_best;
+    a.best_dist = d_best_dist;
+    a.matches = d_matches;
+    a.cap = cap;
+    a.match_counts = d_match_count;
+    {
+        KernelTimer timer(ctx, KID_MERGE_RATIO);
+        hipLaunchKernelGGL(merge_ratio_kernel, dim3((a.rows_max + 255) / 256, 2), dim3(256), 0, ctx->stream, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+    }
+    KernelTimer timer(ctx, KID_RATIO_CROSS);
+    hipLaunchKernelGGL(ratio_cross_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, a);
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
 }

@@ -202,6 +202,76 @@ def test_padded_gather_gloo_world2(tmp_path):
         assert p.wait(timeout=240) == 0
 
 
+_SLAB_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from sfm_amd import allpairs, synth
+from oracle import pyoracle   # the checker stands in for the GPU kernels in this CPU test
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+F, rows = 5, 301
+desc = synth.descriptor_chain(F, rows, 32, seed=23)
+
+# 1. the descriptor stack from per-rank shares (frame f lives on rank f % world)
+per = (F + world - 1) // world
+local = np.zeros((per, rows, 32), np.uint8)
+for s in range(per):
+    if s * world + rank < F:
+        local[s] = desc[s * world + rank]
+stack, nbytes = allpairs.replicate_frames(torch.from_numpy(local), F, rank, world)
+assert stack.shape == (F, rows, 32) and np.array_equal(stack.numpy(), desc)
+assert nbytes == (world - 1) * local.nbytes
+
+# 2. fewer pairs than ranks: every pair split by query rows
+class Slab:
+    ratio = np.float32(0.8)
+    def n_rows(self, f):
+        return rows
+    def knn_slab(self, q, t, lo, hi):
+        idx, dst = pyoracle.knn2_hamming(stack[q].numpy()[lo:hi], stack[t].numpy())
+        return torch.from_numpy(idx.reshape(-1, 2)), torch.from_numpy(dst.reshape(-1, 2))
+    def cross(self, idx_f, dist_f, idx_b, dist_b):
+        i_f, d_f, i_b, d_b = (x.numpy() for x in (idx_f, dist_f, idx_b, dist_b))
+        best_f = np.where((i_f[:, 1] >= 0) & (d_f[:, 0] < self.ratio * d_f[:, 1]), i_f[:, 0], -1)
+        best_b = np.where((i_b[:, 1] >= 0) & (d_b[:, 0] < self.ratio * d_b[:, 1]), i_b[:, 0], -1)
+        out = [(p, c, int(d_f[p, 0])) for c, p in enumerate(best_b) if p >= 0 and best_f[p] == c]
+        return len(out), torch.tensor(out, dtype=torch.int32).reshape(-1, 3)
+
+pairs = np.array([[0, 1]] if world > 1 else [[0, 1], [1, 3]], np.int32)
+def no_pair_matcher(sub):
+    raise AssertionError("the pair partition must not run")
+c, off, m = allpairs.match_all_pairs(pairs, no_pair_matcher, rank, world, slab=Slab())
+np.savez(os.path.join({out!r}, f"slab{{rank}}.npz"), c=c, off=off, m=m.numpy())
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world,port", [(2, "29621"), (3, "29622")])
+def test_slab_partition_and_replication_gloo(tmp_path, oracle, world, port):
+    """One pair, more ranks than pairs: match_all_pairs splits it by query rows; every rank ends
+    with the single-process result.  Also the descriptor stack all-gathered from per-rank shares."""
+    from sfm_amd import synth
+
+    script = tmp_path / "slab_worker.py"
+    script.write_text(_SLAB_WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r))) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    desc = synth.descriptor_chain(5, 301, 32, seed=23)
+    want = oracle.robust_matches(oracle.NORM_HAMMING, desc[0], desc[1], 0.8)
+    want_m = np.stack([want["queryIdx"], want["trainIdx"], want["distance"].astype(np.int32)], 1)
+    assert len(want) > 50
+    for r in range(world):
+        got = np.load(tmp_path / f"slab{r}.npz")
+        np.testing.assert_array_equal(got["c"], [len(want)])
+        np.testing.assert_array_equal(got["off"], [0, len(want)])
+        np.testing.assert_array_equal(got["m"], want_m)
+
+
 def test_bench_roofline_entries():
     """The roofline entries bench.py derives from per-kernel times: the contraction count of
     the matrix-core kernel, the lane-op count of the scalar kernels and the tracker's

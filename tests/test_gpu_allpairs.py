@@ -161,6 +161,85 @@ def test_collectives_with_a_one_rank_rccl_group(env, oracle):
         dist.destroy_process_group()
 
 
+def test_one_pair_in_query_slabs_equals_oracle(env, oracle):
+    """Fewer pairs than GPUs: one 8192 x 8192 pair split by query rows.  The slabs of three
+    ranks computed one after the other on this GPU reassemble to the oracle's findRobustMatches;
+    so does match_all_pairs' slab route on a one-rank group."""
+    import torch
+
+    from sfm_amd import allpairs, capi, synth
+
+    ctx, dev = env
+    desc = synth.descriptor_chain(3, KPS, D, seed=77)
+    d_desc = torch.from_numpy(desc).to(dev)
+    slab = allpairs.HipSlabMatcher(ctx, capi.NORM_HAMMING, d_desc, 0.8)
+    want = oracle.robust_matches(oracle.NORM_HAMMING, desc[2], desc[1], 0.8, threads=0)
+    assert len(want) > 1000
+    world = 3
+    parts = {k: [] for k in ("if", "df", "ib", "db")}
+    for r in range(world):
+        lo, hi = allpairs.slab_bounds(KPS, r, world)
+        i, d_ = slab.knn_slab(2, 1, lo, hi)
+        parts["if"].append(i), parts["df"].append(d_)
+        i, d_ = slab.knn_slab(1, 2, lo, hi)
+        parts["ib"].append(i), parts["db"].append(d_)
+    n, rec = slab.cross(*(torch.cat(parts[k]) for k in ("if", "df", "ib", "db")))
+    got = _records(rec)
+    assert n == len(want)
+    assert np.array_equal(got["queryIdx"], want["queryIdx"]) and np.array_equal(got["trainIdx"], want["trainIdx"])
+    assert np.array_equal(got["distance"], want["distance"].astype(np.uint16))
+    # the same through match_all_pairs (world 1: the slab is the whole frame)
+    c, off, m = allpairs.match_all_pairs(np.array([[2, 1]]), None, 0, 1, shard="slab", slab=slab)
+    assert c.tolist() == [len(want)] and _records(m).tobytes() == got.tobytes()
+    # the raw entry point on ragged sizes: forward 2-NN of 1000 rows against 37, backward of 37 against 1000
+    a, b = desc[0][:1000], desc[1][:37]
+    d_a, d_b = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    fi, fd = torch.empty((1000, 2), dtype=torch.int32, device=dev), torch.empty((1000, 2), dtype=torch.float32, device=dev)
+    bi, bd = torch.empty((37, 2), dtype=torch.int32, device=dev), torch.empty((37, 2), dtype=torch.float32, device=dev)
+    ctx.knn2_dev(capi.NORM_HAMMING, d_a, 1000, D, d_b, 37, D, D, fi, fd)
+    ctx.knn2_dev(capi.NORM_HAMMING, d_b, 37, D, d_a, 1000, D, D, bi, bd)
+    out = torch.zeros((37, 4), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx.ratio_cross_dev(fi, fd, 1000, bi, bd, 37, 0.9, out, 37, cnt)
+    ctx.synchronize()
+    w2 = oracle.robust_matches(oracle.NORM_HAMMING, a, b, 0.9)
+    assert int(cnt.item()) == len(w2)
+    assert out[: len(w2)].cpu().numpy().view(capi.DMATCH_DTYPE).reshape(-1).tobytes() == w2.tobytes()
+
+
+def test_full_window_512_frames(env, oracle):
+    """The sharded configuration at the size it is quoted on: 512 frames x 8192 x 32 B, all
+    130 816 pairs through HipPairMatcher on one rank.  Every pair's count is in range and the
+    offsets are their running sum; one pair in a thousand is compared record by record with the
+    oracle's findRobustMatches."""
+    import torch
+
+    from sfm_amd import allpairs, capi, synth
+
+    ctx, dev = env
+    F = 512
+    desc = synth.descriptor_chain(F, KPS, D, seed=1234)
+    pairs = allpairs.window_pairs(F)
+    assert len(pairs) == 130816
+    d_desc = torch.from_numpy(desc).to(dev)
+    matcher = allpairs.HipPairMatcher(ctx, capi.NORM_HAMMING, d_desc, KPS, D, 0.5)
+    c, off, m = allpairs.match_all_pairs(pairs, matcher, 0, 1)
+    assert c.shape == (len(pairs),) and (c >= 0).all() and (c <= KPS).all()
+    np.testing.assert_array_equal(off, np.concatenate([[0], np.cumsum(c)]))
+    assert m.shape[0] == off[-1]
+    # neighbouring frames share most of their rows; distant ones next to nothing
+    near = c[pairs[:, 1] - pairs[:, 0] == 1]
+    assert near.min() > 1000 and c[pairs[:, 1] - pairs[:, 0] > 40].max() < near.min()
+    rec = _records(m)
+    for i in range(17, len(pairs), 1000):
+        a, b = pairs[i]
+        want = oracle.robust_matches(oracle.NORM_HAMMING, desc[a], desc[b], 0.5, threads=0)
+        got = rec[off[i]: off[i + 1]]
+        assert len(got) == len(want), (a, b)
+        assert np.array_equal(got["queryIdx"], want["queryIdx"]) and np.array_equal(got["trainIdx"], want["trainIdx"])
+        assert np.array_equal(got["distance"], want["distance"].astype(np.uint16))
+
+
 def test_compact_entry_point_edge_cases(env):
     """Empty frames, no pairs, an output buffer that is too small, unsupported norms."""
     import torch

@@ -28,13 +28,21 @@ def main(argv=None):
         n_frames = int(rng.integers(2, 5))
         n_kp = int(rng.choice([40, 300, 2500]))
         rec = int(rng.choice([8, 28]))                     # plain points or cv::KeyPoint records
-        s = synth.triangulation_set(n_kp, seed=int(rng.integers(0, 10 ** 6)), sigma=float(rng.choice([0.0, 0.3, 1.0])))
-        views = [s["p1"], s["p2"]] + [s["p2"] + np.float32(rng.uniform(-4, 4)) for _ in range(n_frames - 2)]
+        # every frame is its own view of one set of 3D points (a frame matched against itself or
+        # against a copy shifted in the image plane has no unique epipolar geometry: which model
+        # wins is then a matter of rounding)
+        s = synth.triangulation_set(n_kp, seed=int(rng.integers(0, 10 ** 6)))
+        sigma = float(rng.choice([0.0, 0.3, 1.0]))
         kps = np.zeros((n_frames, n_kp, rec // 4), np.float32)
         for f in range(n_frames):
-            kps[f, :, :2] = views[f]
+            R = synth.rot_y(float(rng.uniform(-6, 6)))
+            t = np.array([f * 0.8 + rng.uniform(0.3, 0.6), rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3)])
+            x = (s["X"] @ R.T + t) @ s["K"].T
+            kps[f, :, :2] = x[:, :2] / x[:, 2:] + rng.normal(0, sigma, (n_kp, 2))
         n_pairs = int(rng.integers(1, 8))
-        pairs = np.stack([rng.integers(0, n_frames, n_pairs), rng.integers(0, n_frames, n_pairs)], 1).astype(np.int32)
+        a_of = rng.integers(0, n_frames, n_pairs)
+        b_of = (a_of + rng.integers(1, n_frames, n_pairs)) % n_frames      # never the frame itself
+        pairs = np.stack([a_of, b_of], 1).astype(np.int32)
         cap = n_kp
         counts = np.array([int(rng.choice([0, 3, 6, 7, 8, 11, 14, 15, 16, 40, n_kp // 2, n_kp])) for _ in range(n_pairs)],
                           np.int32)

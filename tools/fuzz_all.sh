@@ -23,7 +23,7 @@ run lk_fuzz 1500 21
 run lk_fuzz 400 21 batch
 run lk_fuzz 30 21 big
 run corners_fuzz 2500
-run corners_fuzz 40 x big
+run corners_fuzz 40 big
 run match_pairs_fuzz 1500
 run triangulate_fuzz 1500
 run geometry_fuzz 150

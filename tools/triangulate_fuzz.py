@@ -82,7 +82,8 @@ def main(argv=None):
         finite = np.isfinite(oX).all(axis=1) & well & (np.linalg.norm(oX, axis=1) < 1e3)
         rel = np.linalg.norm(X - oX, axis=1) / np.maximum(np.linalg.norm(oX, axis=1), 1e-300)
         r = float(rel[finite].max()) if finite.any() else 0.0
-        e_ok = np.allclose(err[finite], oerr[finite], rtol=1e-5, atol=1e-8)
+        # reprojection errors of exact data are rounding residue (1e-10 .. 1e-7 px): a millionth of a pixel
+        e_ok = np.allclose(err[finite], oerr[finite], rtol=1e-5, atol=1e-6)
         band = np.abs(oerr - max_err) < 1e-6 * max(1.0, max_err)
         m_ok = np.array_equal(mask[finite & ~band], omask[finite & ~band])
         worst = max(worst, r)
