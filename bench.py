@@ -610,6 +610,7 @@ def run_c4(args, rank, world, local):
     dim = 128
     ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
     res = {}
+    fp32_pass = None
     for name, integer in (("sift_like_integer", True), ("unit_norm_real", False)):
         q, t = synth.float_descriptors(nq, nt, dim=dim, seed=99 + rank, integer=integer)
         d_q = torch.from_numpy(q).to(dev)
@@ -645,6 +646,23 @@ def run_c4(args, rank, world, local):
                      "exhaustive_queries_last_step": ctx.l2_exhaustive_count(),
                      "roofline": roof}
         res[name]["_dt"] = dt
+        if not integer and not os.environ.get("SFM_L2_MFMA"):
+            # the candidate pass on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), same data, same
+            # exact result: the bound the metric names, beside the default fp16 pass
+            os.environ["SFM_L2_MFMA"] = "f32"
+            try:
+                k32 = max(args.steps // 5, 3)
+                dt32, prof32 = timed_steps(step, k32, 2, world, dev, ctx)
+            finally:
+                del os.environ["SFM_L2_MFMA"]
+            ms32, cnt32 = prof32["l2_candidates_kernel"]
+            tf32 = flop / (ms32 / cnt32 * 1e-3) / 1e12
+            fp32_pass = {"ms_per_step": round(1e3 * dt32 / k32, 4), "steps": k32,
+                         "roofline": {"kernel": "l2_candidates_kernel", "operands": "f32", "bound": "mfma",
+                                      "achieved": round(tf32, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(tf32 / MFMA_F32_PEAK_TFLOPS, 4),
+                                      "avg_launch_us": round(1e3 * ms32 / cnt32, 2)},
+                         "exhaustive_queries_last_step": ctx.l2_exhaustive_count()}
     main = res["unit_norm_real"]
     out = {
         "metric": "float-descriptor 2-NN query rows/sec (BASELINE config 4)",
@@ -657,6 +675,8 @@ def run_c4(args, rank, world, local):
         "roofline": main["roofline"],
         "variants": {k: {kk: vv for kk, vv in v.items() if kk != "_dt"} for k, v in res.items()},
     }
+    if fp32_pass is not None:
+        out["fp32_mfma_pass"] = fp32_pass
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(
         "c4", [out["roofline"]["kernel"]])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -686,8 +706,25 @@ def run_c5(args, rank, world, local):
     dev = torch.device("cuda", local)
     F = args.frames
     ctx = capi.Context(local, stream=torch.cuda.current_stream().cuda_stream)
-    desc = synth.descriptor_chain(F, KPS, DESC_BYTES, seed=1234)  # replicated on every rank
-    d_desc = torch.from_numpy(desc).to(dev)
+    # Every rank uploads only the frames f with f % world == rank (the frames it would have
+    # produced or received); one all-gather over the ranks then replicates the stack -- the one
+    # sizeable payload of this configuration, outside the timed region and reported by itself.
+    desc = synth.descriptor_chain(F, KPS, DESC_BYTES, seed=1234)
+    per = (F + world - 1) // world
+    local_frames = np.zeros((per, KPS, DESC_BYTES), np.uint8)
+    mine = desc[rank::world]
+    local_frames[: len(mine)] = mine
+    d_local = torch.from_numpy(local_frames).to(dev)
+    del desc, local_frames
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    d_desc, recv_bytes = allpairs.replicate_frames(d_local, F, rank, world)
+    barrier_sync(world)
+    replicate = {"ms": round(1e3 * max_over_ranks(time.perf_counter() - t0, world, dev), 3),
+                 "bytes_received_per_rank": int(recv_bytes), "stack_bytes": F * KPS * DESC_BYTES,
+                 "collective": "all_gather_into_tensor of per-rank shares (frame f on rank f % N), then a "
+                               "strided copy into frame order" if world > 1 else "none (one rank holds every frame)"}
+    del d_local
     pairs = allpairs.window_pairs(F)
     matcher = allpairs.HipPairMatcher(ctx, capi.NORM_HAMMING, d_desc, KPS, DESC_BYTES, 0.5)
     n_local = len(allpairs.shard_indices(len(pairs), rank, world))
@@ -725,7 +762,10 @@ def run_c5(args, rank, world, local):
         "check": {"gathered_matches": result.get("n"), "sum_of_pair_counts": result.get("sum_counts"),
                   "gathered_bytes": result.get("bytes"),
                   "record": "6 B (u16 prev row, u16 curr row, u16 Hamming distance)"},
+        "replicate": replicate,
     }
+    if result.get("n") != result.get("sum_counts"):
+        raise RuntimeError(f"c5: gathered {result.get('n')} matches, the pair counts sum to {result.get('sum_counts')}")
     ctx.close()
     return out
 
@@ -1130,10 +1170,13 @@ def other_configs(args, rank, world, local):
     import copy
 
     keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "config",
-            "roofline", "cpu_baseline", "check", "ms_per_frame_pair", "kernels")
+            "roofline", "cpu_baseline", "check", "ms_per_frame_pair", "kernels", "variants", "fp32_mfma_pass",
+            "replicate")
     res = {}
     a = copy.copy(args)
-    a.steps, a.warmup, a.frames = 3, 1, 192
+    # the window at the size the configuration is quoted on: 512 frames, 130 816 pairs (one
+    # untimed and one timed pass, about 1.8 s each on one GPU)
+    a.steps, a.warmup, a.frames = 1, 1, 512
     res["c5_window"] = {k: v for k, v in run_c5(a, rank, world, local).items() if k in keep}
     if world == 1:
         a = copy.copy(args)
