@@ -412,6 +412,170 @@ __device__ __forceinline__ bool null_vector_invit3(const double (&At)[4][4], dou
     return pivots_ok && f1 && f2 && f3 && (m3 <= 1e-13 || m3 * m3 < 1e-12 * m2);
 }
 
+// ---- the default solver: inverse iteration on a triangular factor of A ------------------------
+// Householder reflections bring A to R (A = Q R, Q never formed); (R^T R) y = b is two
+// triangular solves.  The rounding of the result then grows with the first power of the
+// system's condition number, not with its square as for a factorisation of A^T A: for
+// baselines far below the depth (consecutive video frames) the null vector agrees with the
+// one-sided Jacobi SVD to ~1e-11 where the normal-equations form gives 1e-7 to 1e-6.
+struct TriFactor {
+    double r01, r02, r03, r12, r13, r23;   // R above the diagonal
+    double i0, i1, i2, i3;                 // reciprocals of the diagonal
+    bool pivots_ok;
+};
+
+__device__ __forceinline__ void qr_factor(const double (&At)[4][4], TriFactor& f) {
+    double c0[4], c1[4], c2[4], c3[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        c0[r] = At[0][r];
+        c1[r] = At[1][r];
+        c2[r] = At[2][r];
+        c3[r] = At[3][r];
+    }
+    constexpr double kFloor = 1e-290;   // keeps the estimates' inputs normal; such systems fail the finite test
+    // reflection 0: column 0, rows 0..3
+    const double n0 = fma(c0[0], c0[0], fma(c0[1], c0[1], fma(c0[2], c0[2], c0[3] * c0[3])));
+    const double rs0 = rsqrt_pos(fmax(n0, kFloor));
+    const double norm0 = n0 * rs0;
+    const double r00 = c0[0] >= 0 ? -norm0 : norm0;
+    const double h0 = c0[0] - r00;                                      // first entry of the reflection vector
+    const double beta0 = rcp_pos(fmax(fma(-r00, c0[0], n0), kFloor));   // 2 / |h|^2
+    auto reflect0 = [&](double (&c)[4]) {
+        const double s = beta0 * fma(h0, c[0], fma(c0[1], c[1], fma(c0[2], c[2], c0[3] * c[3])));
+        c[0] = fma(-s, h0, c[0]);
+        c[1] = fma(-s, c0[1], c[1]);
+        c[2] = fma(-s, c0[2], c[2]);
+        c[3] = fma(-s, c0[3], c[3]);
+    };
+    reflect0(c1);
+    reflect0(c2);
+    reflect0(c3);
+    f.r01 = c1[0];
+    f.r02 = c2[0];
+    f.r03 = c3[0];
+    // reflection 1: column 1, rows 1..3
+    const double n1 = fma(c1[1], c1[1], fma(c1[2], c1[2], c1[3] * c1[3]));
+    const double rs1 = rsqrt_pos(fmax(n1, kFloor));
+    const double norm1 = n1 * rs1;
+    const double r11 = c1[1] >= 0 ? -norm1 : norm1;
+    const double h1 = c1[1] - r11;
+    const double beta1 = rcp_pos(fmax(fma(-r11, c1[1], n1), kFloor));
+    auto reflect1 = [&](double (&c)[4]) {
+        const double s = beta1 * fma(h1, c[1], fma(c1[2], c[2], c1[3] * c[3]));
+        c[1] = fma(-s, h1, c[1]);
+        c[2] = fma(-s, c1[2], c[2]);
+        c[3] = fma(-s, c1[3], c[3]);
+    };
+    reflect1(c2);
+    reflect1(c3);
+    f.r12 = c2[1];
+    f.r13 = c3[1];
+    // reflection 2: column 2, rows 2..3
+    const double n2 = fma(c2[2], c2[2], c2[3] * c2[3]);
+    const double rs2 = rsqrt_pos(fmax(n2, kFloor));
+    const double norm2 = n2 * rs2;
+    const double r22 = c2[2] >= 0 ? -norm2 : norm2;
+    const double h2 = c2[2] - r22;
+    const double beta2 = rcp_pos(fmax(fma(-r22, c2[2], n2), kFloor));
+    const double s2 = beta2 * fma(h2, c3[2], c2[3] * c3[3]);
+    f.r23 = fma(-s2, h2, c3[2]);
+    const double r33 = fma(-s2, c2[3], c3[3]);
+    // The first three pivots are -+ the column norms, whose reciprocal square roots exist
+    // already.  An exactly singular system (noise-free correspondences) has r33 = 0: a last
+    // pivot below 1e-15 of the first one is replaced by that, which leaves the direction the
+    // solves amplify alone.
+    const double floor_r = norm0 * 1e-15 + 1e-300;
+    f.i0 = c0[0] >= 0 ? -rs0 : rs0;
+    f.i1 = c1[1] >= 0 ? -rs1 : rs1;
+    f.i2 = c2[2] >= 0 ? -rs2 : rs2;
+    const double m3 = fabs(r33);
+    const double ri3 = rcp_pos(m3 > floor_r ? m3 : floor_r);
+    f.i3 = r33 < 0 ? -ri3 : ri3;
+    f.pivots_ok = norm0 > floor_r && norm1 > floor_r && norm2 > floor_r;
+}
+
+// (R^T R) x = b
+__device__ __forceinline__ void tri_solve(const TriFactor& f, const double (&b)[4], double (&x)[4]) {
+    const double z0 = b[0] * f.i0;
+    const double z1 = fma(-f.r01, z0, b[1]) * f.i1;
+    const double z2 = fma(-f.r12, z1, fma(-f.r02, z0, b[2])) * f.i2;
+    const double z3 = fma(-f.r23, z2, fma(-f.r13, z1, fma(-f.r03, z0, b[3]))) * f.i3;
+    x[3] = z3 * f.i3;
+    x[2] = fma(-f.r23, x[3], z2) * f.i2;
+    x[1] = fma(-f.r13, x[3], fma(-f.r12, x[2], z1)) * f.i1;
+    x[0] = fma(-f.r03, x[3], fma(-f.r02, x[2], fma(-f.r01, x[1], z0))) * f.i0;
+}
+
+// y scaled to unit norm with the sign that makes it closest to `ref`; returns the move
+__device__ __forceinline__ double unit_towards(double (&y)[4], const double (&ref)[4], bool& finite) {
+    const double n2 = fma(y[0], y[0], fma(y[1], y[1], fma(y[2], y[2], y[3] * y[3])));
+    finite = n2 > 0 && n2 < 1e300;
+    const double dot = fma(y[0], ref[0], fma(y[1], ref[1], fma(y[2], ref[2], y[3] * ref[3])));
+    double inv = rsqrt_pos(finite ? n2 : 1.0);
+    inv = dot < 0 ? -inv : inv;
+    double delta = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        y[k] *= inv;
+        delta = fmax(delta, fabs(y[k] - ref[k]));
+    }
+    return delta;
+}
+
+// Fixed cost: the factor, three solves, and the acceptance test of null_vector_invit3 (with a
+// fixed factor the contamination shrinks by the same q per solve: the last two moves give q and
+// the error of the result as m3 q; accepted when that is below 1e-12).
+__device__ __forceinline__ bool null_vector_qr3(const double (&At)[4][4], double (&v)[4]) {
+    TriFactor f;
+    qr_factor(At, f);
+    const double x0[4] = {0.1, 0.2, 0.9, 0.3};
+    double x1[4], x2[4], x3[4];
+    bool f1, f2, f3;
+    tri_solve(f, x0, x1);
+    (void)unit_towards(x1, x0, f1);
+    tri_solve(f, x1, x2);
+    const double m2 = unit_towards(x2, x1, f2);
+    tri_solve(f, x2, x3);
+    const double m3 = unit_towards(x3, x2, f3);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = x3[k];
+    return f.pivots_ok && f1 && f2 && f3 && (m3 <= 1e-13 || m3 * m3 < 1e-12 * m2);
+}
+
+// The deferred points: the same iteration continued for as long as it takes, for systems whose
+// two smallest singular values are a factor 2 or more apart (contraction q <= 1/4 per solve, at
+// most kMaxTriIt solves).  Returns false for a system without such a gap (q above 0.3 after
+// the third solve, the mismatched correspondences) or one that has not settled: the caller
+// then takes the shifted iteration on A^T A and, after that, the Jacobi SVD.
+constexpr int kMaxTriIt = 24;
+__device__ __forceinline__ bool null_vector_qr_iter(const double (&At)[4][4], double (&v)[4], bool live) {
+    TriFactor f;
+    qr_factor(At, f);
+    double x[4] = {0.1, 0.2, 0.9, 0.3};
+    double prev_move = 1.0;
+    bool done = !live, good = false;
+    for (int it = 0; it < kMaxTriIt; ++it) {
+        double y[4];
+        bool finite;
+        tri_solve(f, x, y);
+        const double move = unit_towards(y, x, finite);
+        if (!done) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = y[k];
+            const bool settled = it >= 2 && (move <= 1e-13 || move * move < 1e-12 * prev_move);
+            const bool hopeless = !finite || !f.pivots_ok || (it >= 2 && move > 0.3 * prev_move && move > 1e-13);
+            good = settled && finite;
+            done = settled || hopeless;
+            prev_move = move;
+        }
+        if (__all(done)) break;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = x[k];
+    return good;
+}
+
 // Division by w, reprojection, mask and colour for correspondence i (reconstruction.cpp:6-39).
 __device__ __forceinline__ void finish_point(const TriArgs& a, int i, const double (&v)[4], double x2,
                                              double y2) {
@@ -462,7 +626,9 @@ __global__ __launch_bounds__(256) void triangulate_dlt_kernel(TriArgs a) {
 // (a single counter would serialise tens of thousands of atomics).
 constexpr int kListBins = 1024;
 
-// Fast path; unsettled points go to the lists.
+// Fast path; unsettled points go to the lists.  kNormalEq: the factorisation of A^T A
+// (SFM_TRIANGULATE_NORMAL_EQ=1, a measurement aid) instead of the triangular factor of A.
+template <bool kNormalEq>
 __global__ __launch_bounds__(256) void triangulate_invit_kernel(TriArgs a, int* bin_count, int* list,
                                                                 int bin_cap) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -471,7 +637,7 @@ __global__ __launch_bounds__(256) void triangulate_invit_kernel(TriArgs a, int* 
     if (live) load_points(a, i, p1, p2);
     double At[4][4], v[4];
     build_system<true>(a, p1.x, p1.y, p2.x, p2.y, At);
-    const bool ok = null_vector_invit3(At, v);
+    const bool ok = kNormalEq ? null_vector_invit3(At, v) : null_vector_qr3(At, v);
     if (live && ok) finish_point(a, i, v, p2.x, p2.y);
     const bool defer = live && !ok;
     const unsigned long long votes = __ballot(defer);
@@ -486,9 +652,11 @@ __global__ __launch_bounds__(256) void triangulate_invit_kernel(TriArgs a, int* 
     }
 }
 
-// The listed points, workgroup b taking bin b (exits at once when its bin is empty):
-// adaptively shifted inverse iteration, and one-sided Jacobi for the points that does not
-// settle either.
+// The listed points, workgroup b taking bin b (exits at once when its bin is empty): the
+// iteration on the triangular factor continued (not with kNormalEq), then adaptively shifted
+// inverse iteration on A^T A for the systems without a clear smallest singular value, and
+// one-sided Jacobi, the reference's own algorithm, for the points that does not settle either.
+template <bool kNormalEq>
 __global__ __launch_bounds__(256) void triangulate_list_kernel(TriArgs a, const int* bin_count,
                                                                const int* list, int bin_cap) {
     const int count = bin_count[blockIdx.x];
@@ -501,7 +669,16 @@ __global__ __launch_bounds__(256) void triangulate_list_kernel(TriArgs a, const 
         load_points(a, i, p1, p2);
         double At[4][4], v[4];
         build_system<false>(a, p1.x, p1.y, p2.x, p2.y, At);
-        const bool ok = null_vector_invit(At, v);
+        bool ok = !kNormalEq && null_vector_qr_iter(At, v, live);
+        if (__any(live && !ok)) {  // wave-uniform: the solver below votes on its loop
+            double vi[4];
+            const bool ok2 = null_vector_invit(At, vi);
+            if (!ok) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = vi[c];
+                ok = ok2;
+            }
+        }
         if (__any(live && !ok)) {  // wave-uniform: the Jacobi sweep loop votes too
             double vj[4];
             null_vector_jacobi(At, vj);
@@ -995,28 +1172,37 @@ struct TriLists {
     int bins, bin_cap;
 };
 
-int launch_triangulation(sfm_ctx* ctx, TriArgs& a, const TriLists& l, bool timed) {
+template <bool kNormalEq>
+int launch_triangulation_t(sfm_ctx* ctx, TriArgs& a, const TriLists& l, bool timed) {
     const int blocks = (a.n + 255) / 256;
     SFM_HIP_CHECK(ctx, hipMemsetAsync(l.bin_count, 0, sizeof(int) * kListBins, ctx->stream));
     if (timed) {
         KernelTimer timer(ctx, KID_TRIANGULATE_DLT);
-        hipLaunchKernelGGL(triangulate_invit_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a,
+        hipLaunchKernelGGL(triangulate_invit_kernel<kNormalEq>, dim3(blocks), dim3(256), 0, ctx->stream, a,
                            l.bin_count, l.list, l.bin_cap);
     } else {
-        hipLaunchKernelGGL(triangulate_invit_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a,
+        hipLaunchKernelGGL(triangulate_invit_kernel<kNormalEq>, dim3(blocks), dim3(256), 0, ctx->stream, a,
                            l.bin_count, l.list, l.bin_cap);
     }
     SFM_HIP_CHECK(ctx, hipGetLastError());
     if (timed) {
         KernelTimer timer(ctx, KID_TRIANGULATE_LIST);
-        hipLaunchKernelGGL(triangulate_list_kernel, dim3(l.bins), dim3(256), 0, ctx->stream, a,
+        hipLaunchKernelGGL(triangulate_list_kernel<kNormalEq>, dim3(l.bins), dim3(256), 0, ctx->stream, a,
                            l.bin_count, l.list, l.bin_cap);
     } else {
-        hipLaunchKernelGGL(triangulate_list_kernel, dim3(l.bins), dim3(256), 0, ctx->stream, a,
+        hipLaunchKernelGGL(triangulate_list_kernel<kNormalEq>, dim3(l.bins), dim3(256), 0, ctx->stream, a,
                            l.bin_count, l.list, l.bin_cap);
     }
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
+}
+
+int launch_triangulation(sfm_ctx* ctx, TriArgs& a, const TriLists& l, bool timed) {
+    static const bool normal_eq = [] {   // measurement aid: the factorisation of A^T A
+        const char* e = getenv("SFM_TRIANGULATE_NORMAL_EQ");
+        return e && e[0] == '1';
+    }();
+    return normal_eq ? launch_triangulation_t<true>(ctx, a, l, timed) : launch_triangulation_t<false>(ctx, a, l, timed);
 }
 
 // Bins in use and lanes that can land in one bin, for n correspondences.
