@@ -1,7 +1,8 @@
 """GPU test of sfm_triangulate_noalloc_dev, the entry point that allocates nothing: its output
 must equal sfm_triangulate_dev's bit for bit (same kernels, the deferred-point lists live in a
 fixed device array instead of the context's workspace), on two calls in a row, the second with
-a smaller input so that stale list contents of the first call would show.
+a smaller input so that stale list contents of the first call would show; and on a fresh
+context the call must not change the device's free memory.
 """
 import numpy as np
 import pytest
@@ -28,6 +29,40 @@ def _run(ctx, fn, s, n, dev, with_image):
        3.0, d_X, d_rgb if with_image else None, d_mask, d_err)
     ctx.synchronize()
     return d_X.cpu().numpy(), d_mask.cpu().numpy(), d_err.cpu().numpy(), d_rgb.cpu().numpy()
+
+
+def test_noalloc_entry_point_allocates_nothing():
+    """On a context that has never run anything (no workspace exists yet) the call must leave
+    the device's free memory as it found it: a call that took the workspace route, or any other
+    hipMalloc, would show as a drop.  Its output is compared with the allocating entry point
+    afterwards."""
+    import torch
+
+    from sfm_amd import capi, synth
+
+    dev = torch.device("cuda", 0)
+    n = 1 << 20      # the largest accepted size: the allocating entry point needs 4 MiB of lists for it
+    s = synth.triangulation_set(n, seed=31, outliers=0.3)
+    d_p1, d_p2 = torch.from_numpy(s["p1"]).to(dev), torch.from_numpy(s["p2"]).to(dev)
+    d_X = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    d_mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    d_X2, d_mask2 = torch.empty_like(d_X), torch.empty_like(d_mask)
+    ctx = capi.Context(0)
+    try:
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(dev)[0]
+        ctx.triangulate_noalloc_dev(s["K"], s["prev_pose"], s["curr_pose"], s["R"], s["t"], d_p1, d_p2, n,
+                                    None, 0, 0, 0, 1e-4, 250.0, 3.0, d_X, None, d_mask, None)
+        ctx.synchronize()
+        assert torch.cuda.mem_get_info(dev)[0] == free_before
+        # the allocating entry point on the same fresh context does take memory (its lists)
+        ctx.triangulate_dev(s["K"], s["prev_pose"], s["curr_pose"], s["R"], s["t"], d_p1, d_p2, n,
+                            None, 0, 0, 0, 1e-4, 250.0, 3.0, d_X2, None, d_mask2, None)
+        ctx.synchronize()
+        assert torch.cuda.mem_get_info(dev)[0] < free_before
+        assert torch.equal(d_X.view(torch.int64), d_X2.view(torch.int64)) and torch.equal(d_mask, d_mask2)
+    finally:
+        ctx.close()
 
 
 def test_noalloc_triangulation_equals_allocating_entry_point():
