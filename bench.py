@@ -524,6 +524,16 @@ def run_framepair(args, rank, world, local):
     if lk_n:
         out["lk_track"] = {"avg_launch_us": round(1e3 * lk_ms / lk_n, 2),
                            "points_per_s": round(P * LK_POINTS / (lk_ms / lk_n * 1e-3), 1)}
+        # the whole tracking stage per step (padding, pyramids, a derivative image where the
+        # window size still has one, the tracker): the tracker of 21 x 21 windows forms the
+        # derivatives itself, so its own time carries work that was another kernel's before
+        stage_ms = sum(prof[k][0] for k in prof if k.startswith("lk_")) / args.steps
+        macs = roof_lk.get("achieved", 0) and roof_lk["achieved"] * 1e12 * (lk_ms / lk_n * 1e-3)
+        out["lk_stage"] = {"ms_per_step": round(stage_ms, 4),
+                           "kernels": sorted(k for k in prof if k.startswith("lk_")),
+                           "achieved": round(macs / (stage_ms * 1e-3) / 1e12, 3) if macs else None,
+                           "unit": "Tlane-op/s over the stage (same multiply-add count as 'roofline')",
+                           "frac_of_valu_peak": round(macs / (stage_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 4) if macs else None}
     if cpu is not None:
         out["cpu_baseline"] = cpu
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

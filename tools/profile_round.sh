@@ -21,7 +21,7 @@ run() { # name, limit, args...
     if [ $rc -ne 0 ]; then tail -5 "$OUT/$name.log"; exit $rc; fi
 }
 
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-other-configs --sustain 0 --one-stream"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-other-configs --no-sequence --sustain 0 --one-stream"
 for wl in framepair c3 c4 f1 f2 f3 vo; do
     run stats_$wl 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -o $wl \
         -- $BENCH --workload $wl --steps 5 --warmup 2
