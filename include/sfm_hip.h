@@ -201,6 +201,11 @@ int sfm_gather_segments_dev(sfm_ctx* ctx, const void* d_src, const int64_t* d_sr
  * OpenCV's default minEigThreshold 1e-4.  Points are interleaved (x, y) floats.
  * err (may be NULL) receives the per-point residual.  The normal-equation sums
  * are accumulated exactly in integers (OpenCV: float, build-dependent order).
+ * Against a float-accumulating run of the same algorithm: a point whose two runs take the
+ * same number of iterations on every pyramid level agrees within 1e-3 px (measured: 3.4e-4)
+ * with the same status; the other points (a stop test decided differently under the two
+ * roundings: 0 to 0.34 % of the points on the tested shapes, 0.32 % of 5000 points at
+ * 1280x720) agree within the termination epsilon.
  * Windows up to 41x41 are supported.  The two images may have different row pitches, as
  * calc accepts them (one of them a region of a larger image): prev_stride and curr_stride are
  * the bytes between rows of each. */
