@@ -40,6 +40,7 @@
 #include <cstdlib>
 
 #include "sfm_internal.h"
+#include <type_traits>
 
 namespace sfm {
 
@@ -58,6 +59,25 @@ constexpr int kBlock = 256;
 constexpr int kTileRows = 64;   // train rows per LDS tile (two 32-row MFMA tiles)
 constexpr int kMaxSplits = 16;  // 4 candidates per split and query, 64 per query at most
 
+// l2_pack_kernel and l2_narrow_kernel leave two maxima per workgroup, slots[2 b] and
+// slots[2 b + 1]: over its rows in the group of its first row, and over its rows in later groups
+// (a workgroup across a frame boundary) -- plain stores; an atomic maximum per workgroup on a
+// per-group address costs more than the packing itself (1250 workgroups, all resident at once:
+// 5 to 12 us per launch).  The largest value of group g is the maximum of the first slots of
+// the workgroups that start in g and of the rows of g that sit in the workgroup before them,
+// which are read from the per-row array (fewer than 32).  NaN values are skipped: their rows
+// never rank.
+struct FoldSet {
+    const float* slots;     // [workgroups][2]
+    const float* per_row;   // [rows]
+    const int32_t* counts;  // rows in use per group, or null: the others do not count
+    float* group;           // [groups]: the result
+    int rows, rows_per_group, groups;
+};
+struct FoldArgs {
+    FoldSet set[2];   // groups of set 0, then of set 1
+};
+
 struct L2Args {
     const float* q_base;  // packed rows of K floats
     const float* t_base;
@@ -74,6 +94,12 @@ struct L2Args {
     int32_t* cand;  // [problem][split][rows_cap][4]
     float* cand_key;  // the candidates' ranking keys ||t||^2 - 2 q.t, same layout
     float* cand_third;  // [problem][split][rows_cap][2]: third-smallest key of each candidate list
+    // fp16 pass: the last fold_groups workgroups of the launch do not rank; they fold what
+    // l2_pack_kernel and l2_narrow_kernel left per workgroup into the groups' largest norms and
+    // residual norms, which the re-score pass reads (a launch of their own would cost more
+    // than they do)
+    FoldArgs fold[2];
+    int fold_groups;
 };
 
 __device__ __forceinline__ void glds16(const void* gptr, void* lptr) {
@@ -92,6 +118,52 @@ __device__ __forceinline__ int select_i(unsigned long long mask, int a, int b) {
     int r;
     asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
     return r;
+}
+
+// ---- largest norm / residual norm of every group of rows (a frame; the queries; the train rows)
+// (four waves per workgroup; sixteen, for a quarter of the slots, take half as long again: 14 against 9 us)
+constexpr int kPackBlock = 256;
+constexpr int kPackRowsPerWave = 8;
+constexpr int kPackRowsPerBlock = (kPackBlock / 64) * kPackRowsPerWave;
+
+// Maxima of two values over the workgroup (up to 16 waves), in every thread.
+__device__ __forceinline__ void block_max2(float& a, float& b) {
+    __shared__ float s_max[16][2];
+    for (int o = 32; o > 0; o >>= 1) {
+        a = fmaxf(a, __shfl_xor(a, o));
+        b = fmaxf(b, __shfl_xor(b, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_max[threadIdx.x >> 6][0] = a;
+        s_max[threadIdx.x >> 6][1] = b;
+    }
+    __syncthreads();
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+        a = fmaxf(a, s_max[w][0]);
+        b = fmaxf(b, s_max[w][1]);
+    }
+    __syncthreads();   // the array may be written again
+}
+
+// (the whole workgroup calls this)
+__device__ __forceinline__ void fold_group(const FoldArgs& f, int g_all) {
+    const bool second = g_all >= f.set[0].groups;
+    const FoldSet& p = f.set[second ? 1 : 0];
+    const int g = second ? g_all - f.set[0].groups : g_all;
+    const long blocks = ((long)p.rows + kPackRowsPerBlock - 1) / kPackRowsPerBlock;
+    const long first_row = (long)g * p.rows_per_group;
+    const long end_row = min((long)p.rows, first_row + p.rows_per_group);
+    // workgroup b starts in the group of row 32 b
+    const long b0 = (first_row + kPackRowsPerBlock - 1) / kPackRowsPerBlock;
+    const long b1 = min(blocks, (first_row + p.rows_per_group + kPackRowsPerBlock - 1) / kPackRowsPerBlock);
+    float v = 0.f, unused = 0.f;
+    for (long b = b0 + threadIdx.x; b < b1; b += blockDim.x) v = fmaxf(v, p.slots[2 * b]);
+    const long head_end = min(end_row, b0 * kPackRowsPerBlock);
+    const long used = p.counts ? p.counts[g] : p.rows_per_group;
+    for (long r = first_row + threadIdx.x; r < head_end; r += blockDim.x)
+        if (r - first_row < used) v = fmaxf(v, p.per_row[r]);
+    block_max2(v, unused);
+    if (threadIdx.x == 0) p.group[g] = v;
 }
 
 template <int K, int NT>
@@ -378,6 +450,12 @@ void l2_candidates_narrow_kernel(L2Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
 
+    if (F16 && (int)blockIdx.x >= (int)gridDim.x - a.fold_groups) {   // (see L2Args)
+        const int g = (int)blockIdx.x - ((int)gridDim.x - a.fold_groups);
+        fold_group(a.fold[0], g);
+        fold_group(a.fold[1], g);
+        return;
+    }
     const int g = blockIdx.x / a.blocks_per_group, inner = blockIdx.x % a.blocks_per_group;
     const int per_dir = a.qtiles * a.splits;
     const int dir = inner / per_dir;
@@ -626,16 +704,39 @@ void l2_candidates_narrow_kernel(L2Args a) {
     }
 }
 
-// Raises *dst (a non-negative float, ordered like its bit pattern; NaN candidates are skipped by
-// the callers' comparisons) to the largest `v` of the workgroup, with at most one atomic.
-__device__ __forceinline__ void block_max_to(float* dst, float v) {
-    __shared__ float s_max[kBlock / 64];
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0 && dst) {
-        for (int w = 1; w < kBlock / 64; ++w) v = fmaxf(v, s_max[w]);
-        if (v > *reinterpret_cast<volatile float*>(dst)) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(v));
+// Sum over the wave, the same value in every lane: quad permutes and row mirrors inside each row
+// of 16 lanes (no LDS traffic), then the four row sums through scalar registers.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_f32(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v = dpp_add_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add_f32<0x141>(v);   // row_half_mirror
+    v = dpp_add_f32<0x140>(v);   // row_mirror: every lane of a row holds the row's sum
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// Group (frame) and position in it of the rows row0 .. row0 + 7 of a wave (row0 wave-uniform;
+// rows past the end repeat the last row): one division for the first row, steps from there.
+__device__ __forceinline__ void walk_rows(int row0, int rows, int rows_per_group, int (&group)[kPackRowsPerWave],
+                                          int (&local)[kPackRowsPerWave]) {
+    const int first = min(row0, rows - 1);
+    int g = first / rows_per_group, l = first - g * rows_per_group;
+#pragma unroll
+    for (int r = 0; r < kPackRowsPerWave; ++r) {
+        group[r] = g;
+        local[r] = l;
+        if (row0 + r + 1 < rows && ++l == rows_per_group) {
+            l = 0;
+            ++g;
+        }
     }
 }
 
@@ -643,8 +744,8 @@ __device__ __forceinline__ void block_max_to(float* dst, float v) {
 // into the layout of the passes in one launch: zero-padded rows of K floats, ||row||^2, for the
 // bfloat16 pass the rows split into 2 K bfloat16 -- the K upper halves xh = bf16(x), then the K
 // lower halves xl = bf16(x - xh), both rounded to nearest even (x - xh is exact in fp32) -- and
-// the largest norm of every group of rows (a frame; the queries; the train rows), which must be
-// zero before the launch; a NaN norm is skipped, its row never ranks anyway.
+// the largest norms a workgroup saw (two slots per workgroup, see FoldSet; rows beyond a
+// group's count and NaN norms are left out).
 struct PackSet {
     const uint8_t* src;
     int rows, rows_per_group;          // row r lies in group r / rows_per_group
@@ -654,92 +755,134 @@ struct PackSet {
     float* norms;                      // [rows]
     float* acc0;                       // [rows]: -||row||^2 / 2, or null
     const int32_t* counts;             // rows in use per group, or null: the rest does not enter the maxima
-    float* group_max;                  // [groups] largest ||row||^2 of every group
+    float* slots;                      // [workgroups of the set][2]
 };
 struct PackArgs {
     PackSet set[2];
     int blocks0;   // workgroups of set 0; the rest serve set 1
     int dim, K;
-    int32_t* clear[2];   // counters of later kernels that this launch zeroes (or null)
-    float* clear_res;    // and the groups' largest residual norms
-    int n_clear_res;
+    int32_t* clear[3];   // counters of later kernels that this launch zeroes (or null)
 };
-constexpr int kPackRowsPerWave = 8;
-
-__global__ __launch_bounds__(kBlock) void l2_pack_kernel(PackArgs a) {
+// ALIGNED: every row starts on an 8-byte boundary and dim is even; SPLIT: the bfloat16 halves are written.
+template <bool ALIGNED, bool SPLIT>
+__global__ __launch_bounds__(kPackBlock) void l2_pack_kernel(PackArgs a) {
     const bool second = (int)blockIdx.x >= a.blocks0;
     const PackSet& p = a.set[second ? 1 : 0];
     const int block = second ? blockIdx.x - a.blocks0 : blockIdx.x;
     const int lane = threadIdx.x & 63;
-    const int row0 = (block * (kBlock / 64) + (threadIdx.x >> 6)) * kPackRowsPerWave;
-    const int block_group = min(block * (kBlock / 64) * kPackRowsPerWave, p.rows - 1) / p.rows_per_group;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int row0 = (block * (kPackBlock / 64) + wave) * kPackRowsPerWave;
+    const int block_group = min(block * kPackRowsPerBlock, p.rows - 1) / p.rows_per_group;
+    int group[kPackRowsPerWave], local[kPackRowsPerWave];
+    walk_rows(row0, p.rows, p.rows_per_group, group, local);
     const int K = a.K;
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < 2 && a.clear[threadIdx.x]) *a.clear[threadIdx.x] = 0;
-        for (int i = threadIdx.x; i < a.n_clear_res; i += kBlock) a.clear_res[i] = 0.f;
-    }
-    // A lane takes element pairs lane and lane + 64 of a row (K <= 256: at most 128 pairs).  All
-    // the loads of the wave's rows go out before the first value is used.
+    if (blockIdx.x == 0 && threadIdx.x < 3 && a.clear[threadIdx.x]) *a.clear[threadIdx.x] = 0;
+    // A lane takes element pairs lane and lane + 64 of a row (K <= 256: at most 128 pairs; the
+    // second pair only exists for K = 256).  All the loads of the wave's rows go out before the
+    // first value is used: a lane past the row's end reads the row's last elements instead and
+    // replaces them by zeros, so no load sits behind a branch of its own.
     typedef float floatx2 __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const int dim = a.dim;
+    const bool second_pair = K > 128;   // wave-uniform
     floatx2 v[kPackRowsPerWave][2];
 #pragma unroll
     for (int r = 0; r < kPackRowsPerWave; ++r) {
-        const int row = min(row0 + r, p.rows - 1);
-        const int group = row / p.rows_per_group;
-        const float* s = reinterpret_cast<const float*>(p.src + (size_t)group * p.group_stride +
-                                                        (size_t)(row - group * p.rows_per_group) * p.row_stride);
+        const float* s = reinterpret_cast<const float*>(p.src + (size_t)group[r] * p.group_stride +
+                                                        (size_t)local[r] * p.row_stride);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            v[r][i] = floatx2{0.f, 0.f};
+            if (i == 1 && !second_pair) continue;
             const int j = 2 * (lane + 64 * i);
-            v[r][i].x = j < a.dim ? s[j] : 0.f;
-            v[r][i].y = j + 1 < a.dim ? s[j + 1] : 0.f;
+            if (ALIGNED) {
+                const floatx2 x = *reinterpret_cast<const floatx2*>(s + max(min(j, dim - 2), 0));
+                v[r][i] = j < dim ? x : floatx2{0.f, 0.f};
+            } else {
+                const float x0 = s[max(min(j, dim - 1), 0)], x1 = s[max(min(j + 1, dim - 1), 0)];
+                v[r][i].x = j < dim ? x0 : 0.f;
+                v[r][i].y = j + 1 < dim ? x1 : 0.f;
+            }
         }
     }
-    float largest = 0.f;
+    float acc[kPackRowsPerWave];
 #pragma unroll
-    for (int r = 0; r < kPackRowsPerWave; ++r) {
-        const int row = row0 + r;
-        if (row >= p.rows) break;   // wave-uniform
-        float acc = 0.f;
+    for (int r = 0; r < kPackRowsPerWave; ++r) acc[r] = 0.f;
+    // (the copy is left out when the caller's rows already are the packed ones: the choice is
+    // made once, outside the loops)
+    auto convert = [&](auto copy) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int j = 2 * (lane + 64 * i);
             if (j < K) {
-                const floatx2 x = v[r][i];
-                if (p.dst) *reinterpret_cast<floatx2*>(p.dst + (size_t)row * K + j) = x;
-                if (p.split) {
-                    bf16x2 h, l;
-                    h.x = (__bf16)x.x;
-                    h.y = (__bf16)x.y;
-                    l.x = (__bf16)(x.x - (float)h.x);
-                    l.y = (__bf16)(x.y - (float)h.y);
-                    *reinterpret_cast<bf16x2*>(p.split + (size_t)row * 2 * K + j) = h;
-                    *reinterpret_cast<bf16x2*>(p.split + (size_t)row * 2 * K + K + j) = l;
+#pragma unroll
+                for (int r = 0; r < kPackRowsPerWave; ++r) {
+                    const int row = row0 + r;
+                    if (row < p.rows) {   // wave-uniform
+                        const floatx2 x = v[r][i];
+                        if (decltype(copy)::value) *reinterpret_cast<floatx2*>(p.dst + (size_t)row * K + j) = x;
+                        if (SPLIT) {
+                            bf16x2 h, l;
+                            h.x = (__bf16)x.x;
+                            h.y = (__bf16)x.y;
+                            l.x = (__bf16)(x.x - (float)h.x);
+                            l.y = (__bf16)(x.y - (float)h.y);
+                            *reinterpret_cast<bf16x2*>(p.split + (size_t)row * 2 * K + j) = h;
+                            *reinterpret_cast<bf16x2*>(p.split + (size_t)row * 2 * K + K + j) = l;
+                        }
+                        acc[r] += x.x * x.x;
+                        acc[r] += x.y * x.y;
+                    }
                 }
-                acc += x.x * x.x;
-                acc += x.y * x.y;
             }
         }
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    };
+    if (p.dst)
+        convert(std::true_type{});
+    else
+        convert(std::false_type{});
+    float largest = 0.f, largest_later = 0.f;
+#pragma unroll
+    for (int r = 0; r < kPackRowsPerWave; ++r) {
+        const int row = row0 + r;
+        if (row >= p.rows) break;   // wave-uniform
+        const float norm = wave_sum_f32(acc[r]);
         if (lane == 0) {
-            p.norms[row] = acc;
-            if (p.acc0) p.acc0[row] = -0.5f * acc;
+            p.norms[row] = norm;
+            if (p.acc0) p.acc0[row] = -0.5f * norm;
         }
         // rows past a frame's count are whatever the caller's buffer holds: they are converted
         // like the others (nothing reads them) but must not set the scale or the error bound
-        const int group = row / p.rows_per_group;
-        const bool in_use = !p.counts || row - group * p.rows_per_group < p.counts[group];
-        // the workgroup raises the maximum of its first row's group with one atomic; a row of
-        // another group (a workgroup across a frame boundary) does so for itself
-        if (group == block_group)
-            largest = in_use && acc > largest ? acc : largest;
-        else if (lane == 0 && in_use && acc > *reinterpret_cast<volatile float*>(p.group_max + group))
-            atomicMax(reinterpret_cast<unsigned*>(p.group_max + group), __float_as_uint(acc));
+        const bool in_use = !p.counts || local[r] < p.counts[group[r]];
+        if (group[r] == block_group)
+            largest = in_use && norm > largest ? norm : largest;
+        else
+            largest_later = in_use && norm > largest_later ? norm : largest_later;
     }
-    // the maximum only grows: a workgroup whose rows do not exceed what is there leaves it alone
-    // (thousands of atomics on one address would take longer than the packing)
-    block_max_to(p.group_max + block_group, largest);
+    block_max2(largest, largest_later);
+    if (threadIdx.x == 0) {
+        p.slots[2 * block] = largest;
+        p.slots[2 * block + 1] = largest_later;
+    }
+}
+
+// The groups' largest norms by a launch of its own: the passes without l2_narrow_kernel, which
+// otherwise does this on the side.
+__global__ __launch_bounds__(kBlock) void l2_group_fold_kernel(FoldArgs f) { fold_group(f, blockIdx.x); }
+
+// The largest norm of all: only for more slots than every workgroup of l2_narrow_kernel
+// would read by itself.
+struct SlotsMaxArgs {
+    const float* slots[2];
+    long n_slots[2];
+    float* out;
+};
+__global__ __launch_bounds__(1024) void l2_slots_max_kernel(SlotsMaxArgs a) {
+    float m = 0.f, unused = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (long k = threadIdx.x; k < a.n_slots[i]; k += 1024) m = fmaxf(m, a.slots[i][k]);
+    block_max2(m, unused);
+    if (threadIdx.x == 0) *a.out = m;
 }
 
 // Packed rows -> single fp16 copies for the fp16 candidate pass, in one launch for up to two
@@ -748,8 +891,10 @@ __global__ __launch_bounds__(kBlock) void l2_pack_kernel(PackArgs a) {
 // pipe's fp32.  Per row: the fp16 row fp16(x s) (round to nearest even); the norm of what the
 // rounding left out, ||x - fp16(x s) / s|| (the differences are exact in fp32; the sum is
 // rounded up by a part in a thousand, and by the most that a pipe reading fp16 denormals as
-// zero could drop); the accumulator start value -||x||^2 s^2 / 2.  Per set the largest residual
-// norm (res_max zero before the launch).  scale_out: s^2 and 1 / s^2.
+// zero could drop); the accumulator start value -||x||^2 s^2 / 2.  Per workgroup the largest
+// residual norms (two slots, see FoldSet).  scale_out: s^2 and 1 / s^2.  The largest norm of all
+// rows, which sets s, is read from the slots l2_pack_kernel left (norm_slots; every workgroup
+// goes through all of them) or, when there are too many for that, from *global_max.
 struct NarrowSet {
     const float* packed;   // [rows][K]
     const float* norms;    // [rows]
@@ -757,93 +902,125 @@ struct NarrowSet {
     _Float16* half;        // [rows][K]
     float* res;            // [rows]
     float* acc0;           // [rows], or null
-    float* group_res;      // [groups] largest residual norm of every group
     int rows_per_group;    // as in PackSet
     const int32_t* counts;
+    float* slots;          // [workgroups of the set][2]
 };
 struct NarrowArgs {
     NarrowSet set[2];
     int blocks0;
     int K;
-    const float* group_max;  // [n_groups] largest ||row||^2 of every group of both sets
-    int n_groups;
+    const float* norm_slots[2];
+    int n_norm_slots[2];       // 0: *global_max holds the largest norm
+    const float* global_max;
     float* scale_out;
 };
+constexpr long kDirectSlots = 8192;   // slots a workgroup of l2_narrow_kernel reads by itself at most
 
-__global__ __launch_bounds__(kBlock) void l2_narrow_kernel(NarrowArgs a) {
+__global__ __launch_bounds__(kPackBlock) void l2_narrow_kernel(NarrowArgs a) {
     typedef float floatx2 __attribute__((ext_vector_type(2)));
     typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
     const bool second = (int)blockIdx.x >= a.blocks0;
     const NarrowSet& p = a.set[second ? 1 : 0];
     const int block = second ? blockIdx.x - a.blocks0 : blockIdx.x;
     const int lane = threadIdx.x & 63;
-    const int row0 = (block * (kBlock / 64) + (threadIdx.x >> 6)) * kPackRowsPerWave;
-    const int block_group = min(block * (kBlock / 64) * kPackRowsPerWave, p.rows - 1) / p.rows_per_group;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int row0 = (block * (kPackBlock / 64) + wave) * kPackRowsPerWave;
+    const int block_group = min(block * kPackRowsPerBlock, p.rows - 1) / p.rows_per_group;
+    int group[kPackRowsPerWave], local[kPackRowsPerWave];
+    walk_rows(row0, p.rows, p.rows_per_group, group, local);
     const int K = a.K;
-    // m: the largest ||row||^2 of all groups; sqrt(m) < 2^e, so |x| s < 2^15 for every element x
-    // of every row
-    float m = 0.f;
-    for (int g = lane; g < a.n_groups; g += 64) m = fmaxf(m, a.group_max[g]);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    int shift = 0;
-    if (m > 0.f && m < INFINITY) {
-        int ex;
-        (void)frexpf(m, &ex);
-        shift = 15 - ((ex + 1) >> 1);
-        shift = shift > 60 ? 60 : shift;   // s^2 stays a float; tiny rows are scaled less
+    // m: the largest ||row||^2 of all (its loads go first; the rows' loads follow before it is used)
+    float m = 0.f, unused = 0.f;
+    const bool direct = a.n_norm_slots[0] + a.n_norm_slots[1] > 0;
+    if (direct) {
+        for (int i = 0; i < 2; ++i)
+            for (int k = threadIdx.x; k < a.n_norm_slots[i]; k += kPackBlock) m = fmaxf(m, a.norm_slots[i][k]);
+    } else {
+        m = *a.global_max;
     }
-    const float s = ldexpf(1.f, shift), inv_s = ldexpf(1.f, -shift);
-    const float s2 = ldexpf(1.f, 2 * shift);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.scale_out[0] = s2;
-        a.scale_out[1] = ldexpf(1.f, -2 * shift);
-    }
+    const bool second_pair = K > 128;   // wave-uniform: pairs 64 .. 127 of a row exist
     floatx2 v[kPackRowsPerWave][2];
+    float norm[kPackRowsPerWave];
 #pragma unroll
     for (int r = 0; r < kPackRowsPerWave; ++r) {
         const int row = min(row0 + r, p.rows - 1);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int j = 2 * (lane + 64 * i);
-            v[r][i] = j < K ? *reinterpret_cast<const floatx2*>(p.packed + (size_t)row * K + j) : floatx2{0.f, 0.f};
+            v[r][i] = floatx2{0.f, 0.f};
+            if (i == 1 && !second_pair) continue;
+            // (a lane past the row reads its last pair instead: no load behind a branch of its own)
+            const int j = min(2 * (lane + 64 * i), K - 2);
+            v[r][i] = *reinterpret_cast<const floatx2*>(p.packed + (size_t)row * K + j);
+        }
+        norm[r] = p.norms[row];
+    }
+    // m: the largest ||row||^2 of all groups; sqrt(m) < 2^e, so |x| s < 2^15 for every element x
+    // of every row
+    if (direct) block_max2(m, unused);
+    int shift = 0;
+    if (m > 0.f && m < INFINITY) {
+        // m = f 2^ex with 0.5 <= f < 1 (frexp); a denormal m counts as 2^-126, which the cap
+        // below covers as well
+        const int ex = (int)((__float_as_uint(m) >> 23) & 255u) - 126;
+        shift = 15 - ((ex + 1) >> 1);
+        shift = shift > 60 ? 60 : shift;   // s^2 stays a float; tiny rows are scaled less
+    }
+    // powers of two between 2^-120 and 2^120, written as their bit patterns
+    auto pow2 = [](int e) { return __uint_as_float((uint32_t)(e + 127) << 23); };
+    const float s = pow2(shift), inv_s = pow2(-shift);
+    const float s2 = pow2(2 * shift);
+    const float denormal_part = sqrtf((float)K) * pow2(-shift - 14);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.scale_out[0] = s2;
+        a.scale_out[1] = pow2(-2 * shift);
+    }
+    float acc[kPackRowsPerWave];
+#pragma unroll
+    for (int r = 0; r < kPackRowsPerWave; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = 2 * (lane + 64 * i);
+        if (j < K) {
+#pragma unroll
+            for (int r = 0; r < kPackRowsPerWave; ++r) {
+                const int row = row0 + r;
+                if (row < p.rows) {   // wave-uniform
+                    const floatx2 x = v[r][i];
+                    halfx2 h;
+                    h.x = (_Float16)(x.x * s);
+                    h.y = (_Float16)(x.y * s);
+                    *reinterpret_cast<halfx2*>(p.half + (size_t)row * K + j) = h;
+                    const float d0 = x.x - (float)h.x * inv_s, d1 = x.y - (float)h.y * inv_s;
+                    acc[r] += d0 * d0;
+                    acc[r] += d1 * d1;
+                }
+            }
         }
     }
-    float largest = 0.f;
+    float largest = 0.f, largest_later = 0.f;
 #pragma unroll
     for (int r = 0; r < kPackRowsPerWave; ++r) {
         const int row = row0 + r;
         if (row >= p.rows) break;   // wave-uniform
-        float acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = 2 * (lane + 64 * i);
-            if (j < K) {
-                const floatx2 x = v[r][i];
-                halfx2 h;
-                h.x = (_Float16)(x.x * s);
-                h.y = (_Float16)(x.y * s);
-                *reinterpret_cast<halfx2*>(p.half + (size_t)row * K + j) = h;
-                const float d0 = x.x - (float)h.x * inv_s, d1 = x.y - (float)h.y * inv_s;
-                acc += d0 * d0;
-                acc += d1 * d1;
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
         // (+ what a matrix pipe that reads fp16 denormals as zero would drop: up to 2^-14 / s
         // in each of the K elements)
-        const float res = (sqrtf(acc) + sqrtf((float)K) * ldexpf(inv_s, -14)) * 1.001f;
+        const float res = (sqrtf(wave_sum_f32(acc[r])) + denormal_part) * 1.001f;
         if (lane == 0) {
             p.res[row] = res;
-            if (p.acc0) p.acc0[row] = -0.5f * p.norms[row] * s2;
+            if (p.acc0) p.acc0[row] = -0.5f * norm[r] * s2;
         }
-        const int group = row / p.rows_per_group;
-        const bool in_use = !p.counts || row - group * p.rows_per_group < p.counts[group];
-        if (group == block_group)
+        const bool in_use = !p.counts || local[r] < p.counts[group[r]];
+        if (group[r] == block_group)
             largest = in_use && res > largest ? res : largest;
-        else if (lane == 0 && in_use && res > *reinterpret_cast<volatile float*>(p.group_res + group))
-            atomicMax(reinterpret_cast<unsigned*>(p.group_res + group), __float_as_uint(res));
+        else
+            largest_later = in_use && res > largest_later ? res : largest_later;
     }
-    block_max_to(p.group_res + block_group, largest);
+    block_max2(largest, largest_later);
+    if (threadIdx.x == 0) {
+        p.slots[2 * block] = largest;
+        p.slots[2 * block + 1] = largest_later;
+    }
 }
 
 struct RescoreArgs {
@@ -870,6 +1047,7 @@ struct RescoreArgs {
     float* knn_dist;
     int32_t* todo_count;  // queries whose result is not proven: count, then (problem, query) pairs
     int32_t* todo;
+    int32_t* exhaustive_done;  // workgroups of the exhaustive pass that have finished (zero between launches)
     int32_t* stat_exhaustive;  // per-context total of such queries since the entry point began
     unsigned long long* partial;  // exhaustive pass: best two of every (entry, slice)
 };
@@ -1099,7 +1277,9 @@ __device__ __forceinline__ int exhaustive_slices(int groups, int grid) {
 // the group's queries, element by element in the order of OpenCV's normL2Sqr, and keeps the
 // best two per query by (distance, train index) -- it meets its rows in ascending order, so a
 // strict comparison leaves the lower index in front; the workgroup's best two go to
-// partial[entry][slice][2], and l2_exhaustive_merge_kernel joins the slices.  K = 64 KPL.
+// partial[entry][slice][2], and the workgroup that finishes last joins the slices into
+// knn_idx / knn_dist.  With an empty list (the usual case) a workgroup reads the count and
+// leaves.  K = 64 KPL.
 template <int KPL>
 __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
     constexpr int K = 64 * KPL;
@@ -1233,15 +1413,17 @@ __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
             r0 = r1;
         }
     }
-}
-
-// Best two of the slices of every listed query -> knn_idx / knn_dist.  `grid` is the size of the
-// l2_exhaustive_kernel launch that wrote the slices.
-__global__ void l2_exhaustive_merge_kernel(RescoreArgs a, int grid) {
-    const int count = *a.todo_count;
-    if (count == 0) return;
-    const int slices = exhaustive_slices((count + kExQueries - 1) / kExQueries, grid);
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x) {
+    // The slices are joined by whichever workgroup finishes last: every workgroup publishes its
+    // stores and counts itself; the one that counts to the size of the launch sees them all.
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(a.exhaustive_done, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid == 0) *a.exhaustive_done = 0;   // for the next launch
+    for (int e = tid; e < count; e += kBlock) {
         unsigned long long k0 = ~0ull, k1 = ~0ull;
         for (int i = 0; i < 2 * slices; ++i) {
             const unsigned long long key = a.partial[2 * (size_t)e * slices + i];
@@ -1347,10 +1529,10 @@ struct L2Scratch {
     float* knn_dist;
 };
 constexpr int kExhaustiveGrid = 1024;
-// scalars: [count of listed queries][spare][largest norm per group ...][largest residual per
-// group ...][s^2][1 / s^2].  The count and the groups' largest norms are cleared before the rows
-// are packed: one memset from the (256-byte aligned) start of the array.
-enum { kScalarTodoCount = 0, kScalarUnused, kScalarGroups };
+// scalars: [count of listed queries][finished workgroups of the exhaustive pass][largest norm
+// of all rows][largest norm per group ...][largest residual per group ...][s^2][1 / s^2].  The
+// two counters are cleared by l2_pack_kernel.
+enum { kScalarTodoCount = 0, kScalarExhaustiveDone, kScalarGlobalMax, kScalarGroups };
 inline float* scratch_group_max(const L2Scratch& s) { return s.scalars + kScalarGroups; }
 inline float* scratch_group_res(const L2Scratch& s) { return s.scalars + kScalarGroups + s.groups; }
 inline float* scratch_scale(const L2Scratch& s) { return s.scalars + kScalarGroups + 2 * s.groups; }
@@ -1365,11 +1547,6 @@ void l2_scratch_carve(Carver& c, const L2Plan& plan, int rows_cap, size_t n_prob
         std::max<size_t>(n_problems * rows_cap, (size_t)kExQueries * kExhaustiveGrid) * 2);
     s->knn_idx = c.take<int32_t>(n_problems * rows_cap * 2);
     s->knn_dist = c.take<float>(n_problems * rows_cap * 2);
-}
-int l2_scratch_clear(sfm_ctx* ctx, const L2Scratch& s) {
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(s.scalars, 0, (kScalarGroups + (size_t)s.groups) * sizeof(float),
-                                      ctx->stream));
-    return SFM_OK;
 }
 static_assert(sizeof(float) == sizeof(int32_t), "the query count lives among the float scalars");
 
@@ -1386,8 +1563,13 @@ struct L2Rows {
     float* norms;    // ||row||^2
     float* acc0;     // start value of the narrow passes' accumulators
     float* res;      // fp16 pass: residual norm
+    float* norm_slots;   // per packing workgroup: two largest norms, two largest residual norms
+    float* res_slots;    // (see FoldSet)
 };
 void l2_rows_carve(Carver& c, size_t rows, int K, L2Rows* r) {
+    const size_t pack_blocks = rows / kPackRowsPerBlock + 1;
+    r->norm_slots = c.take<float>(2 * pack_blocks);
+    r->res_slots = c.take<float>(2 * pack_blocks);
     r->packed = c.take<float>(rows * K);
     r->narrow = c.take<float>(rows * K);
     r->norms = c.take<float>(rows);
@@ -1396,9 +1578,11 @@ void l2_rows_carve(Carver& c, size_t rows, int K, L2Rows* r) {
 }
 
 // Packing of up to two sets of rows for `mode` (a set of zero rows is skipped): one launch, and
-// a second one for the fp16 rows, whose scale depends on the largest norm of all.  The train
-// rows are set 1: their largest norm and residual go to the scalars.  The first four scalars
-// must be zero.
+// a second one for the fp16 rows, whose scale depends on the largest norm of all.  The groups'
+// largest norms go to the scalars (groups of set 0, then of set 1; the train rows are set 1
+// unless set0_is_train), the counters of the later passes are cleared.  fp16 pass: fold[0] and
+// fold[1] say how the groups' largest norms and residual norms are formed from what the two
+// launches left; the candidate pass does that on the side (l2_knn_packed).
 struct L2Source {
     const void* src;
     int rows, rows_per_group;
@@ -1406,11 +1590,8 @@ struct L2Source {
     const int32_t* counts;   // rows in use per group (device), or null
 };
 int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, L2Rows* rows0, const L2Source& src1,
-            L2Rows* rows1, bool set0_is_train, int dim, int K, const L2Scratch& sc) {
-    // after l2_scratch_clear; the launch clears the groups' residual maxima and the context's
-    // count of exhaustive queries for the kernels after it.  Groups: those of set 0, then set 1.
-    const int groups0 = src0.rows > 0 ? (src0.rows + src0.rows_per_group - 1) / src0.rows_per_group : 0;
-    const int rows_per_block = (kBlock / 64) * kPackRowsPerWave;
+            L2Rows* rows1, bool set0_is_train, int dim, int K, const L2Scratch& sc, FoldArgs (&fold)[2]) {
+    fold[0] = fold[1] = FoldArgs{};
     const L2Source* src[2] = {&src0, &src1};
     L2Rows* rows[2] = {rows0, rows1};
     // Rows that already are what the packed copy would be -- K floats wide, back to back,
@@ -1423,45 +1604,88 @@ int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, L2Rows* rows0, cons
             (reinterpret_cast<uintptr_t>(sr.src) & 15) == 0)
             rows[i]->packed = nullptr;
     }
-    const int blocks0 = (src0.rows + rows_per_block - 1) / rows_per_block;
-    const int blocks = blocks0 + (src1.rows + rows_per_block - 1) / rows_per_block;
-    if (blocks <= 0) {   // nothing to pack: only the count of exhaustive queries is reset
+    int set_blocks[2], set_groups[2], rpg[2];
+    for (int i = 0; i < 2; ++i) {
+        rpg[i] = src[i]->rows_per_group > 0 ? src[i]->rows_per_group : 1;
+        set_blocks[i] = (src[i]->rows + kPackRowsPerBlock - 1) / kPackRowsPerBlock;
+        set_groups[i] = src[i]->rows > 0 ? (src[i]->rows + rpg[i] - 1) / rpg[i] : 0;
+    }
+    const int blocks = set_blocks[0] + set_blocks[1];
+    int32_t* counters = reinterpret_cast<int32_t*>(sc.scalars);
+    if (blocks <= 0) {   // nothing to pack: only the counters are reset
         SFM_HIP_CHECK(ctx, hipMemsetAsync(ctx->stats, 0, sizeof(int32_t), ctx->stream));
+        SFM_HIP_CHECK(ctx, hipMemsetAsync(counters, 0, kScalarGlobalMax * sizeof(int32_t), ctx->stream));
         return SFM_OK;
     }
+    if (set_groups[0] + set_groups[1] > sc.groups) return set_error(ctx, SFM_E_INVALID, "more row groups than planned");
     KernelTimer timer(ctx, KID_L2_PACK);
     PackArgs a{};
     NarrowArgs n{};
+    FoldArgs norm_fold{};
     for (int i = 0; i < 2; ++i) {
         const bool train = i == 1 || set0_is_train;
-        a.set[i] = PackSet{static_cast<const uint8_t*>(src[i]->src), src[i]->rows,
-                           src[i]->rows_per_group > 0 ? src[i]->rows_per_group : 1, src[i]->group_stride,
+        const int group0 = i ? set_groups[0] : 0;
+        a.set[i] = PackSet{static_cast<const uint8_t*>(src[i]->src), src[i]->rows, rpg[i], src[i]->group_stride,
                            src[i]->row_stride, rows[i]->packed,   // (null: no copy)
                            mode == kL2Bf16 ? reinterpret_cast<__bf16*>(rows[i]->narrow) : nullptr,
                            rows[i]->norms, mode == kL2Bf16 ? rows[i]->acc0 : nullptr, src[i]->counts,
-                           scratch_group_max(sc) + (i ? groups0 : 0)};
+                           rows[i]->norm_slots};
         if (!rows[i]->packed) rows[i]->packed = const_cast<float*>(static_cast<const float*>(src[i]->src));
         n.set[i] = NarrowSet{rows[i]->packed, rows[i]->norms, src[i]->rows,
                              reinterpret_cast<_Float16*>(rows[i]->narrow), rows[i]->res,
-                             train ? rows[i]->acc0 : nullptr, scratch_group_res(sc) + (i ? groups0 : 0),
-                             src[i]->rows_per_group > 0 ? src[i]->rows_per_group : 1, src[i]->counts};
+                             train ? rows[i]->acc0 : nullptr, rpg[i], src[i]->counts, rows[i]->res_slots};
+        norm_fold.set[i] = FoldSet{rows[i]->norm_slots, rows[i]->norms, src[i]->counts,
+                                   scratch_group_max(sc) + group0, src[i]->rows, rpg[i], set_groups[i]};
+        if (mode == kL2F16)
+            fold[1].set[i] = FoldSet{rows[i]->res_slots, rows[i]->res, src[i]->counts,
+                                     scratch_group_res(sc) + group0, src[i]->rows, rpg[i], set_groups[i]};
     }
-    a.blocks0 = n.blocks0 = blocks0;
-    a.clear[0] = nullptr;
-    a.clear[1] = ctx->stats;
-    a.clear_res = scratch_group_res(sc);
-    a.n_clear_res = sc.groups;
+    a.blocks0 = n.blocks0 = set_blocks[0];
+    a.clear[0] = counters + kScalarTodoCount;
+    a.clear[1] = counters + kScalarExhaustiveDone;
+    a.clear[2] = ctx->stats;
     a.dim = dim;
     a.K = n.K = K;
-    n.group_max = scratch_group_max(sc);
-    n.n_groups = sc.groups;
-    n.scale_out = scratch_scale(sc);
-    hipLaunchKernelGGL(l2_pack_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, a);
+    bool aligned = dim % 2 == 0;   // rows of an even number of floats on 8-byte boundaries
+    for (int i = 0; i < 2; ++i)
+        if (src[i]->rows > 0 && ((reinterpret_cast<uintptr_t>(src[i]->src) | src[i]->row_stride | src[i]->group_stride) & 7))
+            aligned = false;
+    const bool split = mode == kL2Bf16;
+    if (aligned && !split)
+        hipLaunchKernelGGL((l2_pack_kernel<true, false>), dim3(blocks), dim3(kPackBlock), 0, ctx->stream, a);
+    else if (aligned)
+        hipLaunchKernelGGL((l2_pack_kernel<true, true>), dim3(blocks), dim3(kPackBlock), 0, ctx->stream, a);
+    else if (!split)
+        hipLaunchKernelGGL((l2_pack_kernel<false, false>), dim3(blocks), dim3(kPackBlock), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((l2_pack_kernel<false, true>), dim3(blocks), dim3(kPackBlock), 0, ctx->stream, a);
     SFM_HIP_CHECK(ctx, hipGetLastError());
-    if (mode == kL2F16) {
-        hipLaunchKernelGGL(l2_narrow_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, n);
+    if (mode != kL2F16) {
+        hipLaunchKernelGGL(l2_group_fold_kernel, dim3(set_groups[0] + set_groups[1]), dim3(kBlock), 0, ctx->stream,
+                           norm_fold);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+        return SFM_OK;
+    }
+    fold[0] = norm_fold;
+    n.scale_out = scratch_scale(sc);
+    n.global_max = sc.scalars + kScalarGlobalMax;
+    if (2L * blocks <= kDirectSlots) {
+        for (int i = 0; i < 2; ++i) {
+            n.norm_slots[i] = rows[i]->norm_slots;
+            n.n_norm_slots[i] = 2 * set_blocks[i];
+        }
+    } else {
+        SlotsMaxArgs m{};
+        for (int i = 0; i < 2; ++i) {
+            m.slots[i] = rows[i]->norm_slots;
+            m.n_slots[i] = 2L * set_blocks[i];
+        }
+        m.out = sc.scalars + kScalarGlobalMax;
+        hipLaunchKernelGGL(l2_slots_max_kernel, dim3(1), dim3(1024), 0, ctx->stream, m);
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
+    hipLaunchKernelGGL(l2_narrow_kernel, dim3(blocks), dim3(kPackBlock), 0, ctx->stream, n);
+    SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
 }
 
@@ -1471,7 +1695,7 @@ int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, L2Rows* rows0, cons
 int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int squared, const L2Rows& q,
                   const L2Rows& t, size_t frame_rows, int rows_cap, const int32_t* d_counts, int nq_uniform,
                   int nt_uniform, const int32_t* d_pairs, int n_problems, const L2Scratch& s,
-                  int t_group0, bool clear_todo) {
+                  int t_group0, bool clear_todo, const FoldArgs* fold) {
     int32_t* todo_count = reinterpret_cast<int32_t*>(s.scalars + kScalarTodoCount);
     const int narrow_floats = mode == kL2F16 ? plan.K / 2 : plan.K;   // floats of a narrow row
     L2Args a{};
@@ -1493,8 +1717,14 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int sq
     a.cand = s.cand;
     a.cand_key = s.cand_key;
     a.cand_third = s.cand_third;
-    const long grid = (long)a.n_groups * a.blocks_per_group;
+    long grid = (long)a.n_groups * a.blocks_per_group;
     if (grid <= 0) return SFM_OK;
+    if (fold && mode == kL2F16) {   // the groups' largest norms and residual norms, on the side (see L2Args)
+        a.fold[0] = fold[0];
+        a.fold[1] = fold[1];
+        a.fold_groups = fold[0].set[0].groups + fold[0].set[1].groups;
+        grid += a.fold_groups;
+    }
     if (grid > 0x7fffffffL) return set_error(ctx, SFM_E_INVALID, "knn launch too large");
     if (clear_todo) SFM_HIP_CHECK(ctx, hipMemsetAsync(todo_count, 0, sizeof(int32_t), ctx->stream));
     if (plan.K == 64)
@@ -1540,6 +1770,7 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int sq
     r.knn_dist = s.knn_dist;
     r.todo_count = todo_count;
     r.todo = s.todo;
+    r.exhaustive_done = reinterpret_cast<int32_t*>(s.scalars + kScalarExhaustiveDone);
     r.stat_exhaustive = ctx->stats;
     r.partial = s.partial;
     const int nq_max = d_counts ? rows_cap : nq_uniform;
@@ -1562,8 +1793,6 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int sq
         hipLaunchKernelGGL(l2_exhaustive_kernel<2>, dim3(kExhaustiveGrid), dim3(kBlock), 0, ctx->stream, r);
     else
         hipLaunchKernelGGL(l2_exhaustive_kernel<4>, dim3(kExhaustiveGrid), dim3(kBlock), 0, ctx->stream, r);
-    SFM_HIP_CHECK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(l2_exhaustive_merge_kernel, dim3(64), dim3(256), 0, ctx->stream, r, kExhaustiveGrid);
     SFM_HIP_CHECK(ctx, hipGetLastError());
     return SFM_OK;
 }
@@ -1597,14 +1826,14 @@ int l2_knn2_dev(sfm_ctx* ctx, int squared, const float* d_q, int nq, size_t q_st
     // results go straight to the caller's arrays: one problem, so [q][2] is their layout
     sc.knn_idx = d_idx;
     sc.knn_dist = d_dist;
-    SFM_RETURN_IF(l2_scratch_clear(ctx, sc));
     const L2Mode mode = l2_mode();
+    FoldArgs fold[2];
     SFM_RETURN_IF(l2_pack(ctx, mode, L2Source{d_q, nq, nq, 0, q_stride, nullptr}, &q,
                           L2Source{d_t, nt, nt, 0, t_stride, nullptr}, &t,
-                          false, dim, K, sc));
+                          false, dim, K, sc, fold));
     // (groups: the queries, then the train rows)
     SFM_RETURN_IF(l2_knn_packed(ctx, plan, mode, dim, squared, q, t, 0, rows_cap, nullptr, nq, nt, nullptr, 1, sc,
-                                nq > 0 ? 1 : 0, false));
+                                nq > 0 ? 1 : 0, false, fold));
     return SFM_OK;
 }
 
@@ -1656,20 +1885,21 @@ int l2_match_frames_dev(sfm_ctx* ctx, int squared, const float* d_desc, int n_fr
     SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
     Carver c(ws);
     l2_pairs_carve(c, plan, n_frames, rows_per_frame, chunk, &b);
-    SFM_RETURN_IF(l2_scratch_clear(ctx, b.sc));
     const L2Mode mode = l2_mode();
     // every frame in one launch, each serving as query and as train set; rows beyond a frame's
     // count are packed too (they are never read)
     L2Rows spare = b.rows;
+    FoldArgs fold[2];
     SFM_RETURN_IF(l2_pack(ctx, mode, L2Source{d_desc, n_frames * rows_per_frame, rows_per_frame, frame_stride,
                                               (size_t)dim * 4, d_counts},
-                          &b.rows, L2Source{nullptr, 0, 1, 0, 0, nullptr}, &spare, true, dim, plan.K, b.sc));
+                          &b.rows, L2Source{nullptr, 0, 1, 0, 0, nullptr}, &spare, true, dim, plan.K, b.sc,
+                          fold));
     for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
         const int np = chunk < n_pairs - p0 ? chunk : n_pairs - p0;
         const int32_t* pairs = d_pairs + 2 * (size_t)p0;
         SFM_RETURN_IF(l2_knn_packed(ctx, plan, mode, dim, squared, b.rows, b.rows, (size_t)rows_per_frame,
                                     rows_per_frame, d_counts, rows_per_frame, rows_per_frame, pairs, 2 * np,
-                                    b.sc, 0, true));
+                                    b.sc, 0, p0 > 0, p0 == 0 ? fold : nullptr));
         SFM_RETURN_IF(launch_ratio_cross_knn(ctx, b.sc.knn_idx, b.sc.knn_dist, rows_per_frame, d_counts,
                                              rows_per_frame, pairs, np, ratio, b.best, b.best_dist,
                                              d_matches + (size_t)p0 * cap, cap,

@@ -310,6 +310,75 @@ def test_l2_match_pairs_ragged(ctx, oracle, monkeypatch, dim, rows, counts, mode
     assert exhaustive[0] == exhaustive[1]
 
 
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+def test_l2_match_pairs_tiny_frames(ctx, oracle, monkeypatch, mode):
+    """Frames much smaller than the 32 rows a packing workgroup takes: one workgroup then holds
+    rows of several frames (and frames of very different magnitude), and every frame's largest
+    norm comes from rows that are not in a workgroup of its own."""
+    import torch
+
+    from sfm_amd import capi
+
+    monkeypatch.setenv("SFM_L2_MFMA", mode)
+    rng = np.random.default_rng(5)
+    n_frames, rows, dim = 13, 7, 64
+    counts = np.array([7, 3, 0, 5, 7, 1, 7, 6, 2, 7, 7, 4, 7], np.int32)
+    base = rng.standard_normal((rows, dim)).astype(np.float32)
+    stack = np.stack([(base[rng.permutation(rows)] + 0.1 * rng.standard_normal((rows, dim)).astype(np.float32))
+                      * np.float32(2.0 ** (f % 5)) for f in range(n_frames)])
+    for f in range(n_frames):
+        stack[f, counts[f]:] = np.nan      # rows past a frame's count may hold anything
+    pairs = np.array([(i, (i + k) % n_frames) for i in range(n_frames) for k in (1, 2, 5)], np.int32)
+    dev = torch.device("cuda:0")
+    d_desc = torch.from_numpy(stack).to(dev)
+    d_counts, d_pairs = torch.from_numpy(counts).to(dev), torch.from_numpy(pairs).to(dev)
+    d_matches = torch.zeros((len(pairs), rows, 4), dtype=torch.int32, device=dev)
+    d_mc = torch.zeros(len(pairs), dtype=torch.int32, device=dev)
+    ctx.match_pairs_dev(capi.NORM_L2, d_desc, n_frames, rows * dim * 4, rows, d_counts, dim, d_pairs,
+                        len(pairs), 0.9, d_matches, rows, d_mc)
+    ctx.synchronize()
+    mc = d_mc.cpu().numpy()
+    m = d_matches.cpu().numpy().view(capi.DMATCH_DTYPE).reshape(len(pairs), rows)
+    total = 0
+    for p, (i, j) in enumerate(pairs):
+        want = oracle.robust_matches(oracle.NORM_L2, stack[i][: counts[i]], stack[j][: counts[j]], 0.9)
+        assert mc[p] == len(want), (i, j)
+        assert _tuples(m[p][: mc[p]]) == _tuples(want), (i, j)
+        total += len(want)
+    assert total > 20
+
+
+def test_l2_match_pairs_many_rows(ctx, oracle):
+    """More packed rows (44 frames of 3001) than a workgroup of the narrowing launch scans for
+    the largest norm by itself: the separate reduction sets the scale.  The frame with the largest
+    rows is not in any pair."""
+    import torch
+
+    from sfm_amd import capi
+
+    rng = np.random.default_rng(11)
+    n_frames, rows, dim = 44, 3001, 64
+    base = rng.standard_normal((rows, dim)).astype(np.float32)
+    stack = np.empty((n_frames, rows, dim), np.float32)
+    for f in range(n_frames):
+        stack[f] = base[rng.permutation(rows)] + 0.2 * rng.standard_normal((rows, dim)).astype(np.float32)
+    stack[37] *= np.float32(40.0)
+    pairs = np.array([(0, 1), (43, 20)], np.int32)
+    dev = torch.device("cuda:0")
+    d_desc, d_pairs = torch.from_numpy(stack).to(dev), torch.from_numpy(pairs).to(dev)
+    d_matches = torch.zeros((len(pairs), rows, 4), dtype=torch.int32, device=dev)
+    d_mc = torch.zeros(len(pairs), dtype=torch.int32, device=dev)
+    ctx.match_pairs_dev(capi.NORM_L2, d_desc, n_frames, rows * dim * 4, rows, None, dim, d_pairs,
+                        len(pairs), 0.8, d_matches, rows, d_mc)
+    ctx.synchronize()
+    mc = d_mc.cpu().numpy()
+    m = d_matches.cpu().numpy().view(capi.DMATCH_DTYPE).reshape(len(pairs), rows)
+    for p, (i, j) in enumerate(pairs):
+        want = oracle.robust_matches(oracle.NORM_L2, stack[i], stack[j], 0.8)
+        assert len(want) > 500 and mc[p] == len(want), (i, j)
+        assert _tuples(m[p][: mc[p]]) == _tuples(want), (i, j)
+
+
 @pytest.mark.parametrize("integer", [True, False])
 def test_l2_full_size_20000x20000x128(ctx, oracle, integer):
     """The float-matching configuration at the size it is quoted on (20 000 x 20 000 x 128, both
