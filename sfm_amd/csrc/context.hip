@@ -146,8 +146,8 @@ static int create_common(int device, hipStream_t stream, bool own, sfm_ctx** out
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->num_cus = prop.multiProcessorCount;
     sfm::triangulate_scratch_setup(device);
-    e = hipMalloc(reinterpret_cast<void**>(&ctx->stats), 256);
-    if (e == hipSuccess) e = hipMemset(ctx->stats, 0, 256);
+    e = hipMalloc(reinterpret_cast<void**>(&ctx->stats), sfm::kStatsBytes);
+    if (e == hipSuccess) e = hipMemset(ctx->stats, 0, sfm::kStatsBytes);
     if (e != hipSuccess) {
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;

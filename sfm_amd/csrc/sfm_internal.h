@@ -66,7 +66,10 @@ struct sfm_ctx {
     size_t pinned_bytes = 0;
     size_t pinned_used = 0;   // bytes handed out since the stream was last idle
     int32_t* stats = nullptr; // small device buffer of counters kernels add to ([0]: L2 queries sent
-                              // through the exhaustive pass by the last L2 entry point)
+                              // through the exhaustive pass by the last L2 entry point); from
+                              // sfm::kStatsTriBins on: the triangulation's bin counters, which its
+                              // second launch leaves at zero for the next call
+    bool tri_bins_dirty = false;  // a failed launch may have left those counters non-zero
     int num_cus = 256;
     std::string err;
     bool profiling = false;
@@ -75,6 +78,10 @@ struct sfm_ctx {
 };
 
 namespace sfm {
+
+constexpr int kStatsTriBins = 64;     // first of the triangulation's bin counters in sfm_ctx::stats
+constexpr int kStatsTriBinCount = 1024;
+constexpr size_t kStatsBytes = (kStatsTriBins + kStatsTriBinCount) * sizeof(int32_t);
 
 int set_error(sfm_ctx* ctx, int code, const char* fmt, ...);
 

@@ -625,6 +625,7 @@ __global__ __launch_bounds__(256) void triangulate_dlt_kernel(TriArgs a) {
 // kListBins, bin b at list + b * bin_cap): one atomic per wave, spread over many addresses
 // (a single counter would serialise tens of thousands of atomics).
 constexpr int kListBins = 1024;
+static_assert(kListBins == kStatsTriBinCount, "the context keeps one counter per bin");
 
 // Fast path; unsettled points go to the lists.  kNormalEq: the factorisation of A^T A
 // (SFM_TRIANGULATE_NORMAL_EQ=1, a measurement aid) instead of the triangular factor of A.
@@ -656,10 +657,15 @@ __global__ __launch_bounds__(256) void triangulate_invit_kernel(TriArgs a, int* 
 // iteration on the triangular factor continued (not with kNormalEq), then adaptively shifted
 // inverse iteration on A^T A for the systems without a clear smallest singular value, and
 // one-sided Jacobi, the reference's own algorithm, for the points that does not settle either.
+// reset: the workgroup leaves its bin's counter at zero for the next call.
 template <bool kNormalEq>
-__global__ __launch_bounds__(256) void triangulate_list_kernel(TriArgs a, const int* bin_count,
-                                                               const int* list, int bin_cap) {
+__global__ __launch_bounds__(256) void triangulate_list_kernel(TriArgs a, int* bin_count, const int* list,
+                                                               int bin_cap, bool reset) {
     const int count = bin_count[blockIdx.x];
+    if (reset) {
+        __syncthreads();   // every wave has read the count
+        if (threadIdx.x == 0) bin_count[blockIdx.x] = 0;
+    }
     const int* mine = list + (size_t)blockIdx.x * bin_cap;
     for (int k0 = 0; k0 < count; k0 += blockDim.x) {  // workgroup-uniform trip count: the solvers vote
         const int k = k0 + threadIdx.x;
@@ -1165,17 +1171,21 @@ int* g_scratch_ptr[kMaxDevices];        // device address of `scratch` on device
 bool g_scratch_asked[kMaxDevices];      // the lookup ran on device d (it runs at context creation)
 hipError_t g_scratch_rc[kMaxDevices];   // what the lookup returned when it did not yield an address
 
-// Lists and counters of one launch pair.
+// Lists and counters of one launch pair.  persistent: the counters are zero on entry and the
+// second launch leaves them so (the context's own); otherwise they are cleared first.
 struct TriLists {
     int* bin_count;
     int* list;
     int bins, bin_cap;
+    bool persistent;
 };
 
 template <bool kNormalEq>
 int launch_triangulation_t(sfm_ctx* ctx, TriArgs& a, const TriLists& l, bool timed) {
     const int blocks = (a.n + 255) / 256;
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(l.bin_count, 0, sizeof(int) * kListBins, ctx->stream));
+    if (!l.persistent || ctx->tri_bins_dirty)
+        SFM_HIP_CHECK(ctx, hipMemsetAsync(l.bin_count, 0, sizeof(int) * kListBins, ctx->stream));
+    if (l.persistent) ctx->tri_bins_dirty = true;   // until both launches are under way
     if (timed) {
         KernelTimer timer(ctx, KID_TRIANGULATE_DLT);
         hipLaunchKernelGGL(triangulate_invit_kernel<kNormalEq>, dim3(blocks), dim3(256), 0, ctx->stream, a,
@@ -1188,12 +1198,13 @@ int launch_triangulation_t(sfm_ctx* ctx, TriArgs& a, const TriLists& l, bool tim
     if (timed) {
         KernelTimer timer(ctx, KID_TRIANGULATE_LIST);
         hipLaunchKernelGGL(triangulate_list_kernel<kNormalEq>, dim3(l.bins), dim3(256), 0, ctx->stream, a,
-                           l.bin_count, l.list, l.bin_cap);
+                           l.bin_count, l.list, l.bin_cap, l.persistent);
     } else {
         hipLaunchKernelGGL(triangulate_list_kernel<kNormalEq>, dim3(l.bins), dim3(256), 0, ctx->stream, a,
-                           l.bin_count, l.list, l.bin_cap);
+                           l.bin_count, l.list, l.bin_cap, l.persistent);
     }
     SFM_HIP_CHECK(ctx, hipGetLastError());
+    if (l.persistent) ctx->tri_bins_dirty = false;
     return SFM_OK;
 }
 
@@ -1236,12 +1247,13 @@ int run_triangulation(sfm_ctx* ctx, TriArgs& a, const TriLists* fixed) {
     TriLists l;
     list_geometry(n, &l);
     Carver sz(nullptr);
-    sz.take<int>(kListBins);
     sz.take<int>((size_t)l.bins * l.bin_cap);
     void* ws;
     SFM_RETURN_IF(workspace(ctx, sz.total(), &ws));
     Carver c(ws);
-    l.bin_count = c.take<int>(kListBins);
+    // the counters are the context's own: no launch spent on clearing them (4 us of a 0.2 ms call)
+    l.bin_count = ctx->stats + kStatsTriBins;
+    l.persistent = true;
     l.list = c.take<int>((size_t)l.bins * l.bin_cap);
     return launch_triangulation(ctx, a, l, true);
 }
@@ -1349,6 +1361,7 @@ int sfm_triangulate_noalloc_dev(sfm_ctx* ctx, const double* K, const double* pre
     list_geometry(n, &l);
     l.bin_count = ptr;              // cleared by launch_triangulation: the array keeps the
     l.list = ptr + kListBins;       // last call's contents
+    l.persistent = false;
     return run_triangulation(ctx, a, &l);
 }
 
