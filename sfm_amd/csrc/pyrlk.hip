@@ -643,16 +643,29 @@ __device__ __forceinline__ int footprint_rows(uint32_t top, uint32_t bot, const 
 // rows are the last one of the group above and the first one of the group below: they and the
 // two pixel rows travel to it through LDS.
 template <int LPP, int SPL, bool FULL, bool VERT = false, bool FLY = false>
-__global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
-    static_assert(!VERT || (LPP == 16 && SPL == 4 && FULL), "vertical groups: 21 x 21 windows on 16 lanes");
+__global__ __launch_bounds__(256, FLY ? (LPP == 8 ? 2 : 3) : 1) void lk_track_kernel(LkArgs a) {
+    static_assert(!VERT || (FULL && ((LPP == 16 && SPL == 4) || (FLY && LPP == 8 && SPL == 8))),
+                  "vertical groups: 21 x 21 windows as sixteen blocks of four slots on 16 or 8 lanes");
     static_assert(!FLY || VERT, "the derivative path builds on the vertical layout");
     const int lane = threadIdx.x & (LPP - 1);
-    const bool own_rows = VERT && lane == 15;   // the lane whose slots sit side by side
-    // FLY: first window row and segment of the lane's block (lane 15: a block whose loads stay
-    // inside the level; what it computes from them is replaced)
-    const int fly_row0 = own_rows ? 8 : 4 * (lane / 3) + (lane >= 6 ? 1 : 0);
-    const int fly_seg = own_rows ? 0 : lane % 3;
-    __shared__ uint4 xfer[FLY ? 4 * 4 * 3 * 7 : 1];   // per wave, point, segment: 7 x 16 bytes for lane 15
+    // Vertical layouts: the window is sixteen blocks of four slots, block b = lane + LPP k the
+    // k-th of the lane (one per lane on 16 lanes, two on 8: the work per point that does not
+    // depend on the window -- weights, sums over the lanes, the 2 x 2 solve -- is then shared by
+    // eight points per instruction instead of four).  Block 15 is the one whose slots sit side by side.
+    constexpr int NB = VERT ? SPL / 4 : 1;
+    bool own_blk[NB];
+    // FLY: first window row and segment of a block (block 15: a block whose loads stay inside
+    // the level; what it computes from them is replaced)
+    int fly_row0_blk[NB], fly_seg_blk[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int b = lane + LPP * k;
+        own_blk[k] = VERT && b == 15;
+        fly_row0_blk[k] = own_blk[k] ? 8 : 4 * (b / 3) + (b >= 6 ? 1 : 0);
+        fly_seg_blk[k] = own_blk[k] ? 0 : b % 3;
+    }
+    const bool own_rows = own_blk[0];   // (the layouts with one block per lane)
+    __shared__ uint4 xfer[FLY ? (256 / LPP) * 3 * 7 : 1];   // per point and segment: 7 x 16 bytes for block 15
     // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); give each XCD one
     // contiguous eighth of the points, so that an image pair's pyramids are fetched into
     // one L2 instead of all eight.
@@ -685,10 +698,11 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
 #pragma unroll
     for (int s = 0; s < SPL; ++s) {
         if (FLY) {
-            // lane 15: slots 0, 2, 3 are the segments of window row 8; slot 1 does not exist
+            // block 15: slots 0, 2, 3 are the segments of window row 8; slot 1 does not exist
             // (it repeats slot 0's place and counts as invalid below)
-            const int srow = own_rows ? 8 : fly_row0 + s;
-            const int sx0 = (own_rows ? max(s - 1, 0) : fly_seg) * kPxPerSlot;
+            const int k = s / 4, j = s % 4;
+            const int srow = own_blk[k] ? 8 : fly_row0_blk[k] + j;
+            const int sx0 = (own_blk[k] ? max(j - 1, 0) : fly_seg_blk[k]) * kPxPerSlot;
             sgeom[s] = (srow << 8) | sx0;
             continue;
         }
@@ -708,7 +722,7 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
         msk[s].set(valid ? min(kPxPerSlot, a.win_w - sx0) : 0);
     }
     auto slot_valid = [&](int s) {
-        return FLY ? !(own_rows && s == 1) : VERT ? !(own_rows && s == 3) : lane + LPP * s < a.slots;
+        return FLY ? !(own_blk[s / 4] && s % 4 == 1) : VERT ? !(own_rows && s == 3) : lane + LPP * s < a.slots;
     };
     // The rows of all slots of a lane from one image: up[s] / lo[s] are the upper and lower row
     // of slot s.  VERT: five loads by every lane (the first slot's upper row and every slot's
@@ -722,18 +736,23 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
                 lo[s] = load_u8x8(base + (o0 + soff[s] + (unsigned)S));
             }
             return;
-        } else if constexpr (FLY) {   // lane 15: slots 0, 2, 3 side by side; its slot 1 holds rows of no meaning
+        } else if constexpr (FLY) {   // block 15: slots 0, 2, 3 side by side; its slot 1 holds rows of no meaning
             uint2 x2 = make_uint2(0, 0), x3 = x2;
-            if (own_rows) {
-                x2 = load_u8x8(base + (o0 + soff[2]));
-                x3 = load_u8x8(base + (o0 + soff[3]));
+            constexpr int kl = NB - 1;   // block 15 is the last block of its lane
+            if (own_blk[kl]) {
+                x2 = load_u8x8(base + (o0 + soff[4 * kl + 2]));
+                x3 = load_u8x8(base + (o0 + soff[4 * kl + 3]));
             }
-            up[0] = load_u8x8(base + (o0 + soff[0]));
+#pragma unroll
+            for (int k = 0; k < NB; ++k) up[4 * k] = load_u8x8(base + (o0 + soff[4 * k]));
 #pragma unroll
             for (int s = 0; s < SPL; ++s) lo[s] = load_u8x8(base + (o0 + soff[s] + (unsigned)S));
-            up[1] = lo[0];
-            up[2] = own_rows ? x2 : lo[1];
-            up[3] = own_rows ? x3 : lo[2];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                up[4 * k + 1] = lo[4 * k];
+                up[4 * k + 2] = k == kl && own_blk[kl] ? x2 : lo[4 * k + 1];
+                up[4 * k + 3] = k == kl && own_blk[kl] ? x3 : lo[4 * k + 2];
+            }
         } else {
             // lane 15's own loads first, into registers of their own: all seven loads are then in
             // flight together (a load that overwrote a copy of lo[] would have to wait for it)
@@ -799,6 +818,13 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
         uint2 iu[SPL], il[SPL];
         uint4 du[SPL][2], dl[SPL][2];   // VERT: the derivative rows of the lane's slots, loaded once
         if constexpr (FLY) {
+            const RowWeights rw = row_weights(wt);
+            uint4* xq = xfer + ((threadIdx.x / LPP) * 3) * 7;   // this point's three segments
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+            const int blk = lane + LPP * k;
+            const bool own = own_blk[k];
+            const int fly_row0 = fly_row0_blk[k], fly_seg = fly_seg_blk[k];
             // 7 rows (window rows fly_row0 - 1 .. + 5) of the 10 pixels from one column left of the
             // segment, as aligned 16-byte loads (a padded level starts 16-byte aligned and its row
             // pitch is a multiple of 16); the byte shuffle that widens two pixels to 16 bits each
@@ -832,9 +858,9 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
             for (int i = 0; i < 5; ++i) {
                 uint32_t sv[5], dv[5];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    sv[k] = pk_lin_u16<12, 40>(pk_add_u16(hp[i][k], hp[i + 2][k]), hp[i + 1][k]);   // 4 (3, 10, 3)
-                    dv[k] = pk_sub_i16(hp[i + 2][k], hp[i][k]);
+                for (int c = 0; c < 5; ++c) {
+                    sv[c] = pk_lin_u16<12, 40>(pk_add_u16(hp[i][c], hp[i + 2][c]), hp[i + 1][c]);   // 4 (3, 10, 3)
+                    dv[c] = pk_sub_i16(hp[i + 2][c], hp[i][c]);
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -860,12 +886,12 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
                     }
                 }
             }
-            // Window row 8 for lane 15: its upper derivative and pixel rows from the lanes of
-            // rows 4-7 (their row 4 / rows 5, 6 of hp), its lower derivative row from the lanes of
-            // rows 9-12 (their row 0).  A wave's LDS operations complete in order, and every point
-            // has its own 16 lanes and its own part of the array: no barrier.
-            uint4* xq = xfer + ((threadIdx.x >> 4) * 3) * 7;   // this point's three segments
-            if (lane >= 3 && lane < 6) {
+            // Window row 8 for block 15: its upper derivative and pixel rows from the blocks of
+            // rows 4-7 (their row 4 / rows 5, 6 of hp), its lower derivative row from the blocks of
+            // rows 9-12 (their row 0).  A wave's LDS operations complete in order, every point has
+            // its own lanes and its own part of the array, and block 15 is the last one in program
+            // order: no barrier.
+            if (blk >= 3 && blk < 6) {
                 uint4* q = xq + fly_seg * 7;
                 q[0] = make_uint4(dx[4][0], dx[4][1], dx[4][2], dx[4][3]);
                 q[1] = make_uint4(dy[4][0], dy[4][1], dy[4][2], dy[4][3]);
@@ -873,13 +899,13 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
                 q[5] = make_uint4(hp[6][0], hp[6][1], hp[6][2], hp[6][3]);
                 q[6] = make_uint4(hp[5][4], hp[6][4], 0u, 0u);
             }
-            if (lane >= 6 && lane < 9) {
+            if (blk >= 6 && blk < 9) {
                 uint4* q = xq + fly_seg * 7;
                 q[2] = make_uint4(dx[0][0], dx[0][1], dx[0][2], dx[0][3]);
                 q[3] = make_uint4(dy[0][0], dy[0][1], dy[0][2], dy[0][3]);
             }
-            // Slot s reads derivative rows s, s + 1 and pixel rows s + 1, s + 2; slot 3's upper rows
-            // are copies, so that lane 15's slots 0, 2, 3 find three separate pairs of rows.
+            // Slot j reads derivative rows j, j + 1 and pixel rows j + 1, j + 2; slot 3's upper rows
+            // are copies, so that block 15's slots 0, 2, 3 find three separate pairs of rows.
             uint32_t dx3[4], dy3[4], hp4[5];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -887,8 +913,8 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
                 dy3[m] = dy[3][m];
             }
 #pragma unroll
-            for (int k = 0; k < 5; ++k) hp4[k] = hp[4][k];
-            if (own_rows) {
+            for (int c = 0; c < 5; ++c) hp4[c] = hp[4][c];
+            if (k == NB - 1 && own) {
                 auto put4 = [](uint32_t (&d)[4], const uint4& v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; };
                 auto put5 = [](uint32_t (&d)[5], const uint4& v, uint32_t e) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; d[4] = e; };
                 const uint4 t0 = xq[6], t1 = xq[7 + 6], t2 = xq[14 + 6];
@@ -899,41 +925,40 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
                 put4(dx3, xq[14 + 0]);   put4(dy3, xq[14 + 1]);   put4(dx[4], xq[14 + 2]); put4(dy[4], xq[14 + 3]);
                 put5(hp4, xq[14 + 4], t2.x);                      put5(hp[5], xq[14 + 5], t2.y);
             }
-            const RowWeights rw = row_weights(wt);
 #pragma unroll
-            for (int s = 0; s < SPL; ++s) {
-                SlotWin& w = win[s];
-                const uint32_t(&ht)[5] = s == 3 ? hp4 : hp[s + 1];
-                const uint32_t(&hb)[5] = hp[s + 2];
-                const uint32_t(&xt)[4] = s == 3 ? dx3 : dx[s];
-                const uint32_t(&yt)[4] = s == 3 ? dy3 : dy[s];
-                const uint32_t(&xb)[4] = dx[s + 1];
-                const uint32_t(&yb)[4] = dy[s + 1];
-                // window pixel j has its footprint at columns j + 1, j + 2 of hp
+            for (int j = 0; j < 4; ++j) {
+                SlotWin& w = win[4 * k + j];
+                const uint32_t(&ht)[5] = j == 3 ? hp4 : hp[j + 1];
+                const uint32_t(&hb)[5] = hp[j + 2];
+                const uint32_t(&xt)[4] = j == 3 ? dx3 : dx[j];
+                const uint32_t(&yt)[4] = j == 3 ? dy3 : dy[j];
+                const uint32_t(&xb)[4] = dx[j + 1];
+                const uint32_t(&yb)[4] = dy[j + 1];
+                // window pixel p has its footprint at columns p + 1, p + 2 of hp
                 constexpr int kRound = 1 << (W_BITS - 5 - 1);
                 int si[kPxPerSlot];
 #pragma unroll
-                for (int j = 0; j < kPxPerSlot; ++j) {
-                    const int k = (j + 1) >> 1;
-                    const uint32_t top = (j & 1) ? ht[k] : next_pair(ht[k], ht[k + 1]);
-                    const uint32_t bot = (j & 1) ? hb[k] : next_pair(hb[k], hb[k + 1]);
-                    si[j] = footprint_rows(top, bot, rw, kRound);
+                for (int p = 0; p < kPxPerSlot; ++p) {
+                    const int c = (p + 1) >> 1;
+                    const uint32_t top = (p & 1) ? ht[c] : next_pair(ht[c], ht[c + 1]);
+                    const uint32_t bot = (p & 1) ? hb[c] : next_pair(hb[c], hb[c + 1]);
+                    si[p] = footprint_rows(top, bot, rw, kRound);
                 }
                 w.i01 = pack_shr9(si[0], si[1]);
                 w.i23 = pack_shr9(si[2], si[3]);
                 w.i45 = pack_shr9(si[4], si[5]);
                 w.i6 = si[6] >> (W_BITS - 5);
-                // derivative of window pixel j from derivative columns j, j + 1
+                // derivative of window pixel p from derivative columns p, p + 1
                 int sx[kPxPerSlot], sy[kPxPerSlot];
 #pragma unroll
-                for (int j = 0; j < kPxPerSlot; ++j) {
-                    const int m = j >> 1;
-                    const uint32_t xtp = (j & 1) ? next_pair(xt[m], xt[m + 1]) : xt[m];
-                    const uint32_t xbp = (j & 1) ? next_pair(xb[m], xb[m + 1]) : xb[m];
-                    const uint32_t ytp = (j & 1) ? next_pair(yt[m], yt[m + 1]) : yt[m];
-                    const uint32_t ybp = (j & 1) ? next_pair(yb[m], yb[m + 1]) : yb[m];
-                    sx[j] = footprint_rows(xtp, xbp, rw, 1 << (W_BITS + 1));
-                    sy[j] = footprint_rows(ytp, ybp, rw, 1 << (W_BITS + 1));
+                for (int p = 0; p < kPxPerSlot; ++p) {
+                    const int m = p >> 1;
+                    const uint32_t xtp = (p & 1) ? next_pair(xt[m], xt[m + 1]) : xt[m];
+                    const uint32_t xbp = (p & 1) ? next_pair(xb[m], xb[m + 1]) : xb[m];
+                    const uint32_t ytp = (p & 1) ? next_pair(yt[m], yt[m + 1]) : yt[m];
+                    const uint32_t ybp = (p & 1) ? next_pair(yb[m], yb[m + 1]) : yb[m];
+                    sx[p] = footprint_rows(xtp, xbp, rw, 1 << (W_BITS + 1));
+                    sy[p] = footprint_rows(ytp, ybp, rw, 1 << (W_BITS + 1));
                 }
                 w.x01 = pack_hi16(sx[0], sx[1]);
                 w.x23 = pack_hi16(sx[2], sx[3]);
@@ -943,8 +968,8 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
                 w.y23 = pack_hi16(sy[2], sy[3]);
                 w.y45 = pack_hi16(sy[4], sy[5]);
                 w.y6 = sy[6] >> 16;
-                if (s == 1) {   // lane 15's slot 1 does not exist: no derivatives, no contribution
-                    const uint32_t keep = own_rows ? 0u : 0xFFFFFFFFu;
+                if (j == 1 && k == NB - 1) {   // block 15's slot 1 does not exist: no derivatives, no contribution
+                    const uint32_t keep = own ? 0u : 0xFFFFFFFFu;
                     w.x01 &= keep;
                     w.x23 &= keep;
                     w.x45 &= keep;
@@ -958,6 +983,7 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
                 pA[1] = mad24(w.x6, w.y6, sdot2(w.x45, w.y45, sdot2(w.x23, w.y23, sdot2(w.x01, w.y01, pA[1]))));
                 pA[2] = mad24(w.y6, w.y6, sdot2(w.y45, w.y45, sdot2(w.y23, w.y23, sdot2(w.y01, w.y01, pA[2]))));
             }
+            }   // blocks of the lane
         } else {
         if constexpr (VERT) {
             load_rows8(I, obase, soff, S, iu, il);
@@ -1430,11 +1456,18 @@ int lk_track_pyramids(sfm_ctx* ctx, const LkGeom& g, const uint8_t* pyr_prev, co
     a.status = d_status;
     a.err = d_err;
     KernelTimer timer(ctx, KID_LK_TRACK);
-    static const bool eight_lanes = [] {   // measurement aid: eight lanes per point
+    static const int lanes_wanted = [] {   // measurement aid: lanes per point (8 or 16)
         const char* e = getenv("SFM_LK_LANES");
-        return e && atoi(e) == 8;
+        return e ? atoi(e) : 0;
     }();
-    if (a.slots <= 64 && a.slots > 56 && eight_lanes && win_w % kPxPerSlot == 0 && deriv_image) {
+    const bool eight_lanes = lanes_wanted == 8;
+    if (!deriv_image && lanes_wanted != 16) {
+        // 21 x 21 windows, derivatives formed in the tracker: eight lanes per point, two blocks of
+        // four slots each; four waves per workgroup, eight points per wave
+        const long waves = (long)n_pairs * ((n + 7) / 8);
+        const dim3 grid((unsigned)((((waves + 3) / 4 + 7) / 8) * 8));
+        hipLaunchKernelGGL((lk_track_kernel<8, 8, true, true, true>), grid, blk, 0, ctx->stream, a);
+    } else if (a.slots <= 64 && a.slots > 56 && eight_lanes && win_w % kPxPerSlot == 0 && deriv_image) {
         const long waves = (long)n_pairs * ((n + 7) / 8);
         const dim3 grid((unsigned)((((waves + 3) / 4 + 7) / 8) * 8));
         hipLaunchKernelGGL((lk_track_kernel<8, 8, true>), grid, blk, 0, ctx->stream, a);
