@@ -530,6 +530,13 @@ struct SlotWin {
     int i6, x6, y6;
 };
 
+// The seventh pixels of two slots side by side (slot 2 t in the low half, 2 t + 1 in the high
+// half): half the registers of three singles per slot, and one 16-bit dot product per sum
+// instead of two multiply-adds.
+struct SlotTail {
+    uint32_t i, x, y;
+};
+
 // Which of a slot's 7 pixels lie inside the window: 0xFFFF per pixel.  FULL (the window width
 // is a multiple of 7, e.g. 21): a slot is inside as a whole or not at all, and its mask is
 // rebuilt from one comparison where it is needed instead of living in four registers.
@@ -570,6 +577,8 @@ __device__ __forceinline__ uint32_t pack_shr9(int s0, int s1) {
 // as three pairs and a single.  The sums are at least 1: the only negative weight is -1.
 // The two rows sit at base + o and base + o + S; base is wave-uniform and both offsets are
 // 32-bit, so the loads need no 64-bit address arithmetic per lane.
+// RAW6: p6 is the seventh pixel's footprint sum before the shift (the caller packs two of them).
+template <bool RAW6 = false>
 __device__ __forceinline__ void window_interp(uint2 a, uint2 b, const Weights& wt,
                                               uint32_t& p01, uint32_t& p23, uint32_t& p45, int& p6) {
     const uint32_t c0 = col_pair<0>(a, b), c1 = col_pair<1>(a, b), c2 = col_pair<2>(a, b),
@@ -579,14 +588,16 @@ __device__ __forceinline__ void window_interp(uint2 a, uint2 b, const Weights& w
     const int s0 = footprint(c0, c1, wt, kRound), s1 = footprint(c1, c2, wt, kRound);
     const int s2 = footprint(c2, c3, wt, kRound), s3 = footprint(c3, c4, wt, kRound);
     const int s4 = footprint(c4, c5, wt, kRound), s5 = footprint(c5, c6, wt, kRound);
-    p6 = footprint(c6, c7, wt, kRound) >> (W_BITS - 5);
+    const int s6 = footprint(c6, c7, wt, kRound);
+    p6 = RAW6 ? s6 : s6 >> (W_BITS - 5);
     p01 = pack_shr9(s0, s1);
     p23 = pack_shr9(s2, s3);
     p45 = pack_shr9(s4, s5);
 }
+template <bool RAW6 = false>
 __device__ __forceinline__ void window_interp(const uint8_t* base, unsigned o, int S, const Weights& wt,
                                               uint32_t& p01, uint32_t& p23, uint32_t& p45, int& p6) {
-    window_interp(load_u8x8(base + o), load_u8x8(base + (o + (unsigned)S)), wt, p01, p23, p45, p6);
+    window_interp<RAW6>(load_u8x8(base + o), load_u8x8(base + (o + (unsigned)S)), wt, p01, p23, p45, p6);
 }
 
 // ---- derivative windows formed in the tracker (21 x 21 windows) -----------------------------
@@ -643,7 +654,7 @@ __device__ __forceinline__ int footprint_rows(uint32_t top, uint32_t bot, const 
 // rows are the last one of the group above and the first one of the group below: they and the
 // two pixel rows travel to it through LDS.
 template <int LPP, int SPL, bool FULL, bool VERT = false, bool FLY = false>
-__global__ __launch_bounds__(256, FLY ? (LPP == 8 ? 2 : 3) : 1) void lk_track_kernel(LkArgs a) {
+__global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
     static_assert(!VERT || (FULL && ((LPP == 16 && SPL == 4) || (FLY && LPP == 8 && SPL == 8))),
                   "vertical groups: 21 x 21 windows as sixteen blocks of four slots on 16 or 8 lanes");
     static_assert(!FLY || VERT, "the derivative path builds on the vertical layout");
@@ -691,21 +702,38 @@ __global__ __launch_bounds__(256, FLY ? (LPP == 8 ? 2 : 3) : 1) void lk_track_ke
     const uint8_t* pyrJ = a.pyr_curr + (size_t)to * g.block;
     const uint32_t* pyrD = a.deriv + (size_t)pair * g.block;
 
-    // slot geometry of this lane: (window row << 8 | first window column) per slot
-    int sgeom[SPL];
-    SlotWin win[SPL];
+    // slot geometry of this lane: (window row << 8 | first window column) per slot (FLY: formed
+    // from the blocks' rows and segments where it is needed)
+    int sgeom[FLY ? 1 : SPL];
+    // Two blocks per lane: the windows of the first block are parked in LDS while the second
+    // block's are set up, and read back slot by slot in every iteration (nine 16-byte vectors
+    // per lane, lane-major: no bank conflicts, no exchange between lanes).  The registers of a
+    // lane then hold one block's windows at a time, and three waves fit a SIMD.
+    constexpr bool PARK = FLY && NB == 2;
+    __shared__ uint4 parked[PARK ? 4 * 9 * 64 : 1];
+    uint4* const park = parked + (threadIdx.x >> 6) * (9 * 64) + (threadIdx.x & 63);
+    SlotWin win[PARK ? 4 : SPL];
+    SlotTail tail[FLY ? SPL / 2 : 1];   // FLY: the slots' seventh pixels, in pairs
+    // slot s of the lane: from the registers, or (parked) from LDS; y45 of the four parked slots
+    // travel together
+    auto slot_window = [&](int s, const uint4& parked_y45) -> SlotWin {
+        if constexpr (PARK) {
+            if (s < 4) {
+                const uint4 a0 = park[(2 * s) * 64], a1 = park[(2 * s + 1) * 64];
+                SlotWin w;
+                w.i01 = a0.x; w.i23 = a0.y; w.i45 = a0.z; w.x01 = a0.w;
+                w.x23 = a1.x; w.x45 = a1.y; w.y01 = a1.z; w.y23 = a1.w;
+                w.y45 = s == 0 ? parked_y45.x : s == 1 ? parked_y45.y : s == 2 ? parked_y45.z : parked_y45.w;
+                return w;
+            }
+            return win[s - 4];
+        } else {
+            return win[s];
+        }
+    };
     SlotMask<FULL> msk[SPL];
 #pragma unroll
-    for (int s = 0; s < SPL; ++s) {
-        if (FLY) {
-            // block 15: slots 0, 2, 3 are the segments of window row 8; slot 1 does not exist
-            // (it repeats slot 0's place and counts as invalid below)
-            const int k = s / 4, j = s % 4;
-            const int srow = own_blk[k] ? 8 : fly_row0_blk[k] + j;
-            const int sx0 = (own_blk[k] ? max(j - 1, 0) : fly_seg_blk[k]) * kPxPerSlot;
-            sgeom[s] = (srow << 8) | sx0;
-            continue;
-        }
+    for (int s = 0; s < (FLY ? 0 : SPL); ++s) {
         if (VERT) {
             // lane 15's fourth slot does not exist: it repeats the third one's place (loads stay
             // inside the level) and counts as invalid below
@@ -811,7 +839,20 @@ __global__ __launch_bounds__(256, FLY ? (LPP == 8 ? 2 : 3) : 1) void lk_track_ke
         // offset of each slot inside a window at this level's row pitch
         unsigned soff[SPL];
 #pragma unroll
-        for (int s = 0; s < SPL; ++s) soff[s] = (unsigned)((sgeom[s] >> 8) * S + (sgeom[s] & 0xFF));
+        for (int s = 0; s < SPL; ++s) {
+            if constexpr (FLY) {
+                // a block's slots sit one below the other; block 15: slots 0, 2, 3 are the segments
+                // of window row 8, slot 1 does not exist (it repeats slot 0's place and counts as
+                // invalid).  Written so that only a block's first row and column are kept from one
+                // level to the next.
+                const int k = s / 4, j = s % 4;
+                const int below = fly_row0_blk[k] * S + fly_seg_blk[k] * kPxPerSlot + j * S;
+                const int beside = 8 * S + (j > 1 ? j - 1 : 0) * kPxPerSlot;
+                soff[s] = (unsigned)(own_blk[k] ? beside : below);
+            } else {
+                soff[s] = (unsigned)((sgeom[s] >> 8) * S + (sgeom[s] & 0xFF));
+            }
+        }
 
         int pA[3] = {0, 0, 0};
         const unsigned obase = (unsigned)((ipy + g.bh) * S + ipx + g.bw);
@@ -925,9 +966,10 @@ __global__ __launch_bounds__(256, FLY ? (LPP == 8 ? 2 : 3) : 1) void lk_track_ke
                 put4(dx3, xq[14 + 0]);   put4(dy3, xq[14 + 1]);   put4(dx[4], xq[14 + 2]); put4(dy[4], xq[14 + 3]);
                 put5(hp4, xq[14 + 4], t2.x);                      put5(hp[5], xq[14 + 5], t2.y);
             }
+            int i6e = 0, x6e = 0, y6e = 0;   // an even slot's seventh sums wait for its odd partner
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                SlotWin& w = win[4 * k + j];
+                SlotWin& w = win[PARK ? j : 4 * k + j];
                 const uint32_t(&ht)[5] = j == 3 ? hp4 : hp[j + 1];
                 const uint32_t(&hb)[5] = hp[j + 2];
                 const uint32_t(&xt)[4] = j == 3 ? dx3 : dx[j];
@@ -947,7 +989,6 @@ __global__ __launch_bounds__(256, FLY ? (LPP == 8 ? 2 : 3) : 1) void lk_track_ke
                 w.i01 = pack_shr9(si[0], si[1]);
                 w.i23 = pack_shr9(si[2], si[3]);
                 w.i45 = pack_shr9(si[4], si[5]);
-                w.i6 = si[6] >> (W_BITS - 5);
                 // derivative of window pixel p from derivative columns p, p + 1
                 int sx[kPxPerSlot], sy[kPxPerSlot];
 #pragma unroll
@@ -963,25 +1004,51 @@ __global__ __launch_bounds__(256, FLY ? (LPP == 8 ? 2 : 3) : 1) void lk_track_ke
                 w.x01 = pack_hi16(sx[0], sx[1]);
                 w.x23 = pack_hi16(sx[2], sx[3]);
                 w.x45 = pack_hi16(sx[4], sx[5]);
-                w.x6 = sx[6] >> 16;
                 w.y01 = pack_hi16(sy[0], sy[1]);
                 w.y23 = pack_hi16(sy[2], sy[3]);
                 w.y45 = pack_hi16(sy[4], sy[5]);
-                w.y6 = sy[6] >> 16;
                 if (j == 1 && k == NB - 1) {   // block 15's slot 1 does not exist: no derivatives, no contribution
                     const uint32_t keep = own ? 0u : 0xFFFFFFFFu;
                     w.x01 &= keep;
                     w.x23 &= keep;
                     w.x45 &= keep;
-                    w.x6 &= (int)keep;
                     w.y01 &= keep;
                     w.y23 &= keep;
                     w.y45 &= keep;
-                    w.y6 &= (int)keep;
                 }
-                pA[0] = mad24(w.x6, w.x6, sdot2(w.x45, w.x45, sdot2(w.x23, w.x23, sdot2(w.x01, w.x01, pA[0]))));
-                pA[1] = mad24(w.x6, w.y6, sdot2(w.x45, w.y45, sdot2(w.x23, w.y23, sdot2(w.x01, w.y01, pA[1]))));
-                pA[2] = mad24(w.y6, w.y6, sdot2(w.y45, w.y45, sdot2(w.y23, w.y23, sdot2(w.y01, w.y01, pA[2]))));
+                pA[0] = sdot2(w.x45, w.x45, sdot2(w.x23, w.x23, sdot2(w.x01, w.x01, pA[0])));
+                pA[1] = sdot2(w.x45, w.y45, sdot2(w.x23, w.y23, sdot2(w.x01, w.y01, pA[1])));
+                pA[2] = sdot2(w.y45, w.y45, sdot2(w.y23, w.y23, sdot2(w.y01, w.y01, pA[2])));
+                if (j & 1) {
+                    SlotTail& tl = tail[2 * k + j / 2];
+                    tl.i = pack_shr9(i6e, si[6]);
+                    tl.x = pack_hi16(x6e, sx[6]);
+                    tl.y = pack_hi16(y6e, sy[6]);
+                    if (j == 1 && k == NB - 1) {   // (block 15's slot 1 again: the high halves)
+                        const uint32_t keep = own ? 0x0000FFFFu : 0xFFFFFFFFu;
+                        tl.x &= keep;
+                        tl.y &= keep;
+                    }
+                    pA[0] = sdot2(tl.x, tl.x, pA[0]);
+                    pA[1] = sdot2(tl.x, tl.y, pA[1]);
+                    pA[2] = sdot2(tl.y, tl.y, pA[2]);
+                } else {
+                    i6e = si[6];
+                    x6e = sx[6];
+                    y6e = sy[6];
+                }
+            }
+            if constexpr (PARK) {
+                if (k == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        park[(2 * j) * 64] = make_uint4(win[j].i01, win[j].i23, win[j].i45, win[j].x01);
+                        park[(2 * j + 1) * 64] = make_uint4(win[j].x23, win[j].x45, win[j].y01, win[j].y23);
+                    }
+                    park[8 * 64] = make_uint4(win[0].y45, win[1].y45, win[2].y45, win[3].y45);
+                    // (the next block's loads and shuffles stay behind this block's arithmetic)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             }   // blocks of the lane
         } else {
@@ -1130,18 +1197,34 @@ __global__ __launch_bounds__(256, FLY ? (LPP == 8 ? 2 : 3) : 1) void lk_track_ke
                 held_x = inx;
                 held_y = iny;
             }
+            int j6even = 0;   // FLY: an even slot's seventh sum waits for its odd partner
+            uint4 parked_y45 = make_uint4(0, 0, 0, 0);
+            if constexpr (PARK) parked_y45 = park[8 * 64];
 #pragma unroll
             for (int s = 0; s < SPL; ++s) {
-                const SlotWin& w = win[s];
+                const SlotWin w = slot_window(s, parked_y45);
                 uint32_t j01, j23, j45;
                 int j6;
-                window_interp(ja[s], jb[s], wt, j01, j23, j45, j6);
+                window_interp<FLY>(ja[s], jb[s], wt, j01, j23, j45, j6);
                 // mismatch J - I; the derivative pairs are 0 outside the window
                 const uint32_t d01 = pk_sub_i16(j01, w.i01), d23 = pk_sub_i16(j23, w.i23),
                                d45 = pk_sub_i16(j45, w.i45);
-                const int d6 = j6 - w.i6;
-                pb[0] = mad24(d6, w.x6, sdot2(d45, w.x45, sdot2(d23, w.x23, sdot2(d01, w.x01, pb[0]))));
-                pb[1] = mad24(d6, w.y6, sdot2(d45, w.y45, sdot2(d23, w.y23, sdot2(d01, w.y01, pb[1]))));
+                if constexpr (FLY) {
+                    pb[0] = sdot2(d45, w.x45, sdot2(d23, w.x23, sdot2(d01, w.x01, pb[0])));
+                    pb[1] = sdot2(d45, w.y45, sdot2(d23, w.y23, sdot2(d01, w.y01, pb[1])));
+                    if (s & 1) {
+                        const SlotTail& tl = tail[s / 2];
+                        const uint32_t d6 = pk_sub_i16(pack_shr9(j6even, j6), tl.i);
+                        pb[0] = sdot2(d6, tl.x, pb[0]);
+                        pb[1] = sdot2(d6, tl.y, pb[1]);
+                    } else {
+                        j6even = j6;
+                    }
+                } else {
+                    const int d6 = j6 - w.i6;
+                    pb[0] = mad24(d6, w.x6, sdot2(d45, w.x45, sdot2(d23, w.x23, sdot2(d01, w.x01, pb[0]))));
+                    pb[1] = mad24(d6, w.y6, sdot2(d45, w.y45, sdot2(d23, w.y23, sdot2(d01, w.y01, pb[1]))));
+                }
             }
             float b1, b2;
             if (LPP == 64) {
@@ -1180,9 +1263,11 @@ __global__ __launch_bounds__(256, FLY ? (LPP == 8 ? 2 : 3) : 1) void lk_track_ke
                 wt = bilinear_weights(ex - inx, ey - iny);
                 int perr[1] = {0};
                 const unsigned ebase = (unsigned)((iny + g.bh) * S + inx + g.bw);
+                uint4 parked_y45 = make_uint4(0, 0, 0, 0);
+                if constexpr (PARK) parked_y45 = park[8 * 64];
 #pragma unroll
                 for (int s = 0; s < SPL; ++s) {
-                    const SlotWin& w = win[s];
+                    const SlotWin w = slot_window(s, parked_y45);
                     const bool valid = slot_valid(s);
                     const uint32_t m01 = msk[s].p01(valid), m23 = msk[s].p23(valid), m45 = msk[s].p45(valid);
                     const int m6 = msk[s].p6(valid);
@@ -1197,7 +1282,13 @@ __global__ __launch_bounds__(256, FLY ? (LPP == 8 ? 2 : 3) : 1) void lk_track_ke
                         const int lo = (int)(short)(dd[k] & 0xFFFF), hi = (int)dd[k] >> 16;
                         perr[0] += abs(lo) + abs(hi);
                     }
-                    perr[0] += abs((j6 - w.i6) & m6);
+                    if constexpr (FLY) {   // the seventh pixel of I sits in its pair's half
+                        const uint32_t ip = tail[s / 2].i;
+                        const int i6 = (s & 1) ? (int)(ip >> 16) : (int)(ip & 0xFFFFu);
+                        perr[0] += abs((j6 - i6) & m6);
+                    } else {
+                        perr[0] += abs((j6 - w.i6) & m6);
+                    }
                 }
                 // Sum of |diff| stays below 2^24 for windows up to 41x41, so the float
                 // accumulation of the reference is exact and equals this integer sum.
