@@ -668,13 +668,16 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
     // FLY: first window row and segment of a block (block 15: a block whose loads stay inside
     // the level; what it computes from them is replaced)
     int fly_row0_blk[NB], fly_seg_blk[NB];
+    auto block_geometry = [&](int lane_) {
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        const int b = lane + LPP * k;
-        own_blk[k] = VERT && b == 15;
-        fly_row0_blk[k] = own_blk[k] ? 8 : 4 * (b / 3) + (b >= 6 ? 1 : 0);
-        fly_seg_blk[k] = own_blk[k] ? 0 : b % 3;
-    }
+        for (int k = 0; k < NB; ++k) {
+            const int b = lane_ + LPP * k;
+            own_blk[k] = VERT && b == 15;
+            fly_row0_blk[k] = own_blk[k] ? 8 : 4 * (b / 3) + (b >= 6 ? 1 : 0);
+            fly_seg_blk[k] = own_blk[k] ? 0 : b % 3;
+        }
+    };
+    block_geometry(lane);
     const bool own_rows = own_blk[0];   // (the layouts with one block per lane)
     __shared__ uint4 xfer[FLY ? (256 / LPP) * 3 * 7 : 1];   // per point and segment: 7 x 16 bytes for block 15
     // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); give each XCD one
@@ -807,6 +810,14 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
 
     for (int level = g.levels; level >= 0; --level) {
         const int lw = g.w[level], lh = g.h[level], S = g.stride[level];
+        if constexpr (NB > 1) {
+            // formed afresh at every level (a handful of instructions): kept from level to level, the
+            // blocks' rows, columns and what the compiler derives from them take registers that the
+            // iterations need
+            int lane_ = lane;
+            asm volatile("" : "+v"(lane_));
+            block_geometry(lane_);
+        }
         // first element of the padded level: all window offsets below are >= 0
         const size_t pad0 = g.img_off[level] - (size_t)g.bh * S - g.bw;
         const uint8_t* I = pyrI + pad0;
