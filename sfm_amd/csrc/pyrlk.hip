@@ -653,8 +653,9 @@ __device__ __forceinline__ int footprint_rows(uint32_t top, uint32_t bot, const 
 // 13-16, 17-20 of a segment; lane 15 owns the three slots of window row 8, whose two derivative
 // rows are the last one of the group above and the first one of the group below: they and the
 // two pixel rows travel to it through LDS.
-template <int LPP, int SPL, bool FULL, bool VERT = false, bool FLY = false>
-__global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
+// WAVES: waves per workgroup (the launch's block size is 64 WAVES).
+template <int LPP, int SPL, bool FULL, bool VERT = false, bool FLY = false, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
     static_assert(!VERT || (FULL && ((LPP == 16 && SPL == 4) || (FLY && LPP == 8 && SPL == 8))),
                   "vertical groups: 21 x 21 windows as sixteen blocks of four slots on 16 or 8 lanes");
     static_assert(!FLY || VERT, "the derivative path builds on the vertical layout");
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
     };
     block_geometry(lane);
     const bool own_rows = own_blk[0];   // (the layouts with one block per lane)
-    __shared__ uint4 xfer[FLY ? (256 / LPP) * 3 * 7 : 1];   // per point and segment: 7 x 16 bytes for block 15
+    __shared__ uint4 xfer[FLY ? (64 * WAVES / LPP) * 3 * 7 : 1];   // per point and segment: 7 x 16 bytes for block 15
     // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); give each XCD one
     // contiguous eighth of the points, so that an image pair's pyramids are fetched into
     // one L2 instead of all eight.
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
     // wave-uniform (scalar registers, 32-bit lane offsets).
     constexpr int kPerWave = 64 / LPP;
     const int waves_per_pair = (a.n + kPerWave - 1) / kPerWave;
-    const int wave_id = __builtin_amdgcn_readfirstlane(pblock * 4 + (int)(threadIdx.x >> 6));
+    const int wave_id = __builtin_amdgcn_readfirstlane(pblock * WAVES + (int)(threadIdx.x >> 6));
     const int pair = wave_id / waves_per_pair;
     if (pair >= a.n_pairs) return;  // wave-uniform
     const int local_raw = (wave_id - pair * waves_per_pair) * kPerWave + (int)(threadIdx.x & 63) / LPP;
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(256, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
     // per lane, lane-major: no bank conflicts, no exchange between lanes).  The registers of a
     // lane then hold one block's windows at a time, and three waves fit a SIMD.
     constexpr bool PARK = FLY && NB == 2;
-    __shared__ uint4 parked[PARK ? 4 * 9 * 64 : 1];
+    __shared__ uint4 parked[PARK ? WAVES * 9 * 64 : 1];
     uint4* const park = parked + (threadIdx.x >> 6) * (9 * 64) + (threadIdx.x & 63);
     SlotWin win[PARK ? 4 : SPL];
     SlotTail tail[FLY ? SPL / 2 : 1];   // FLY: the slots' seventh pixels, in pairs
@@ -1567,8 +1568,23 @@ int lk_track_pyramids(sfm_ctx* ctx, const LkGeom& g, const uint8_t* pyr_prev, co
         // 21 x 21 windows, derivatives formed in the tracker: eight lanes per point, two blocks of
         // four slots each; four waves per workgroup, eight points per wave
         const long waves = (long)n_pairs * ((n + 7) / 8);
-        const dim3 grid((unsigned)((((waves + 3) / 4 + 7) / 8) * 8));
-        hipLaunchKernelGGL((lk_track_kernel<8, 8, true, true, true>), grid, blk, 0, ctx->stream, a);
+        static const int wg_waves = [] {   // measurement aid: waves per workgroup (1, 2 or 4)
+            const char* e = getenv("SFM_LK_WG_WAVES");
+            return e ? atoi(e) : 1;
+        }();
+        // (one wave per workgroup, 866 / 858 / 845 us with four / two / one: a workgroup takes its
+        // place on a SIMD as soon as one wave's registers are free, and the launch's last round of
+        // workgroups leaves the chip partly empty for a shorter time)
+        if (wg_waves == 4) {
+            const dim3 grid((unsigned)((((waves + 3) / 4 + 7) / 8) * 8));
+            hipLaunchKernelGGL((lk_track_kernel<8, 8, true, true, true, 4>), grid, dim3(256), 0, ctx->stream, a);
+        } else if (wg_waves == 1) {
+            const dim3 grid((unsigned)(((waves + 7) / 8) * 8));
+            hipLaunchKernelGGL((lk_track_kernel<8, 8, true, true, true, 1>), grid, dim3(64), 0, ctx->stream, a);
+        } else {
+            const dim3 grid((unsigned)((((waves + 1) / 2 + 7) / 8) * 8));
+            hipLaunchKernelGGL((lk_track_kernel<8, 8, true, true, true, 2>), grid, dim3(128), 0, ctx->stream, a);
+        }
     } else if (a.slots <= 64 && a.slots > 56 && eight_lanes && win_w % kPxPerSlot == 0 && deriv_image) {
         const long waves = (long)n_pairs * ((n + 7) / 8);
         const dim3 grid((unsigned)((((waves + 3) / 4 + 7) / 8) * 8));
