@@ -236,10 +236,11 @@ def lk_roofline(prof, n_pairs, iters_per_point):
             "iterations_source": "cpu_baseline leg of this run" if iters_per_point else "constant",
             "compulsory_hbm_bytes": compulsory,
             "compulsory_hbm_GBps": round(compulsory / sec / 1e9, 1),
-            "second_limit": "vector issue: about 7100 vector instructions per wave of four points "
-                            "(SQ_INSTS_VALU, tools/pmc_sq.sh), most of them half-rate byte shuffles and 16-bit "
-                            "dot products that the multiply-add count does not see; the CU's vector memory "
-                            "path is busy 34 % of the kernel's cycles (TA_TA_BUSY, tools/pmc_ta.sh)",
+            "second_limit": "vector issue: about 12 250 vector instructions per wave of eight points "
+                            "(SQ_INSTS_VALU, tools/pmc_sq.sh; 7100 per wave of four with sixteen lanes per "
+                            "point, SFM_LK_LANES=16), most of them byte shuffles and 16-bit dot products that "
+                            "the multiply-add count does not see; the SIMDs issue one of them in about 85 % "
+                            "of their cycles",
             "traffic": None}
 
 
