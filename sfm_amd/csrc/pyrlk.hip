@@ -957,16 +957,9 @@ __global__ __launch_bounds__(64 * WAVES, FLY ? 3 : 1) void lk_track_kernel(LkArg
                 q[2] = make_uint4(dx[0][0], dx[0][1], dx[0][2], dx[0][3]);
                 q[3] = make_uint4(dy[0][0], dy[0][1], dy[0][2], dy[0][3]);
             }
-            // Slot j reads derivative rows j, j + 1 and pixel rows j + 1, j + 2; slot 3's upper rows
-            // are copies, so that block 15's slots 0, 2, 3 find three separate pairs of rows.
-            uint32_t dx3[4], dy3[4], hp4[5];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                dx3[m] = dx[3][m];
-                dy3[m] = dy[3][m];
-            }
-#pragma unroll
-            for (int c = 0; c < 5; ++c) hp4[c] = hp[4][c];
+            // Slot j reads derivative rows j, j + 1 and pixel rows j + 1, j + 2.  Block 15's slots
+            // 0 and 2 find their rows in place of rows 0 .. 3 (1 .. 4 of the pixels); the upper rows
+            // of its slot 3 replace row 3 (4) once slot 2 has used it, see below.
             if (k == NB - 1 && own) {
                 auto put4 = [](uint32_t (&d)[4], const uint4& v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; };
                 auto put5 = [](uint32_t (&d)[5], const uint4& v, uint32_t e) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; d[4] = e; };
@@ -975,17 +968,31 @@ __global__ __launch_bounds__(64 * WAVES, FLY ? 3 : 1) void lk_track_kernel(LkArg
                 put5(hp[1], xq[4], t0.x);                         put5(hp[2], xq[5], t0.y);
                 put4(dx[2], xq[7 + 0]);  put4(dy[2], xq[7 + 1]);  put4(dx[3], xq[7 + 2]);  put4(dy[3], xq[7 + 3]);
                 put5(hp[3], xq[7 + 4], t1.x);                     put5(hp[4], xq[7 + 5], t1.y);
-                put4(dx3, xq[14 + 0]);   put4(dy3, xq[14 + 1]);   put4(dx[4], xq[14 + 2]); put4(dy[4], xq[14 + 3]);
-                put5(hp4, xq[14 + 4], t2.x);                      put5(hp[5], xq[14 + 5], t2.y);
+                put4(dx[4], xq[14 + 2]); put4(dy[4], xq[14 + 3]);
+                put5(hp[5], xq[14 + 5], t2.y);
             }
             int i6e = 0, x6e = 0, y6e = 0;   // an even slot's seventh sums wait for its odd partner
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (k == NB - 1 && j == 3) {
+                    // block 15, slot 3: its upper rows (segment 2) take the place of the rows that
+                    // slot 2 has just used -- a select per register, every lane reads
+                    const uint4 vx = xq[14 + 0], vy = xq[14 + 1], vh = xq[14 + 4], vt = xq[14 + 6];
+                    const uint32_t nx[4] = {vx.x, vx.y, vx.z, vx.w}, ny[4] = {vy.x, vy.y, vy.z, vy.w};
+                    const uint32_t nh[5] = {vh.x, vh.y, vh.z, vh.w, vt.x};
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        dx[3][m] = own ? nx[m] : dx[3][m];
+                        dy[3][m] = own ? ny[m] : dy[3][m];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) hp[4][c] = own ? nh[c] : hp[4][c];
+                }
                 SlotWin& w = win[PARK ? j : 4 * k + j];
-                const uint32_t(&ht)[5] = j == 3 ? hp4 : hp[j + 1];
+                const uint32_t(&ht)[5] = hp[j + 1];
                 const uint32_t(&hb)[5] = hp[j + 2];
-                const uint32_t(&xt)[4] = j == 3 ? dx3 : dx[j];
-                const uint32_t(&yt)[4] = j == 3 ? dy3 : dy[j];
+                const uint32_t(&xt)[4] = dx[j];
+                const uint32_t(&yt)[4] = dy[j];
                 const uint32_t(&xb)[4] = dx[j + 1];
                 const uint32_t(&yb)[4] = dy[j + 1];
                 // window pixel p has its footprint at columns p + 1, p + 2 of hp
