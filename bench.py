@@ -183,12 +183,19 @@ def timed_steps(step, steps, warmup, world, dev, ctx, more_ctx=(), profile_step=
     streams), with the library's per-kernel timing off: its HIP events around every launch
     would sit in the timed streams.  The per-kernel times come from a second pass of K steps
     after the timed region (`profile_step`, default the same step) with the events on."""
+    # ranks that share one card (rehearsal) take seconds per step: say so while they run
+    rehearsal = bool(os.environ.get("SFM_BENCH_REHEARSE"))
     for _ in range(warmup):
         step()
     barrier_sync(world)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
         step()
+        if rehearsal:
+            import torch
+
+            torch.cuda.synchronize()
+            print(f"rehearsal: step {i + 1} of {steps}", file=sys.stderr, flush=True)
     barrier_sync(world)
     dt = time.perf_counter() - t0
     ctxs = tuple(profile_ctxs) if profile_ctxs is not None else (ctx,) + tuple(more_ctx)
