@@ -637,22 +637,23 @@ __device__ __forceinline__ int footprint_rows(uint32_t top, uint32_t bot, const 
     return sdot2(bot, w.bot, sdot2_k(top, w.top, round));
 }
 
-// LPP = lanes per point: 64 (one point per wave) or 16 (four points per wave, one per
-// DPP row; the per-point scalar work is then shared by four points per instruction).
+// LPP = lanes per point: 64 (one point per wave), 16 (four points per wave, one per DPP row; the
+// per-point scalar work is then shared by four points per instruction) or, with FLY, 8 (eight
+// points per wave: a lane then takes two of the blocks described below, see the kernel).
 // VERT (21 x 21 windows on 16 lanes): a lane's four slots are the same seven columns of four
 // consecutive window rows (lanes 0..14: rows 4 (lane / 3) .. + 3 of segment lane % 3), so the
 // lower image row of one slot is the upper row of the next and five row loads serve four
 // slots instead of eight; lane 15 takes the three slots of window row 20 and loads their
 // upper rows by itself.
-// FLY (21 x 21 windows on 16 lanes, the default for them): the vertical layout again, and no
-// derivative image is read.  Scharr and the bilinear interpolation are both exact integer
+// FLY (21 x 21 windows, the default for them, on 8 lanes or 16): the vertical layout again, and
+// no derivative image is read.  Scharr and the bilinear interpolation are both exact integer
 // linear maps, so a lane forms the derivatives at the 5 x 8 integer positions its four slots
 // touch from 7 rows of 10 pixels of the level itself (packed 16-bit arithmetic on pairs of
 // adjacent columns), zeroes the positions outside the image, as the derivative image would be
-// there, and interpolates them like loaded ones.  Lanes 0..14 own window rows 0-3, 4-7, 9-12,
-// 13-16, 17-20 of a segment; lane 15 owns the three slots of window row 8, whose two derivative
-// rows are the last one of the group above and the first one of the group below: they and the
-// two pixel rows travel to it through LDS.
+// there, and interpolates them like loaded ones.  Blocks 0..14 (one per lane on 16 lanes) own
+// window rows 0-3, 4-7, 9-12, 13-16, 17-20 of a segment; block 15 owns the three slots of window
+// row 8, whose two derivative rows are the last one of the group above and the first one of the
+// group below: they and the two pixel rows travel to it through LDS.
 // WAVES: waves per workgroup (the launch's block size is 64 WAVES).
 template <int LPP, int SPL, bool FULL, bool VERT = false, bool FLY = false, int WAVES = 4>
 __global__ __launch_bounds__(64 * WAVES, FLY ? 3 : 1) void lk_track_kernel(LkArgs a) {
