@@ -71,6 +71,7 @@ struct CornerArgs {
     int32_t* info;          // [image][3]
     float* eig;             // [h][w]
     unsigned* max_bits;     // ordered bits of the image maximum
+    unsigned* tile_max;     // [image][tile]: the maximum of every tile of corner_eig_kernel, or null
     unsigned long long* keys;     // [cap] appended candidates
     unsigned long long* sorted;   // [cap]
     int32_t* rank;          // [h][w]: -1 where no candidate, else rank | state << 30
@@ -183,11 +184,30 @@ __global__ __launch_bounds__(256) void corner_eig_kernel(CornerArgs batch) {
         a.eig[(size_t)y * a.w + x] = e;
         best = max(best, ordered_bits(e));
     }
+    if (!batch.tile_max) return;   // (the response image alone was asked for)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
     if ((tid & 63) == 0) atomicMax(&s_max, best);
     __syncthreads();
-    if (tid == 0 && s_max) atomicMax(a.max_bits, s_max);
+    // One slot per tile, folded by corner_max_kernel: an atomic maximum per workgroup on the
+    // image's word (900 workgroups per 1280 x 720 image, all in flight) took two thirds of
+    // this kernel's time.
+    if (tid == 0)
+        batch.tile_max[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s_max;
+}
+
+// The image maxima from the tiles' maxima: one workgroup per image.
+__global__ __launch_bounds__(256) void corner_max_kernel(CornerArgs batch, int tiles) {
+    __shared__ unsigned s_max;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    unsigned best = 0;
+    for (int i = threadIdx.x; i < tiles; i += 256) best = max(best, batch.tile_max[(size_t)blockIdx.x * tiles + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, best);
+    __syncthreads();
+    if (threadIdx.x == 0) batch.max_bits[(size_t)blockIdx.x * kCtrlWords] = s_max;
 }
 
 constexpr int kPickRows = 32;  // rows per workgroup of the candidate pass (8 per wave)
@@ -648,7 +668,9 @@ struct CornerBuffers {
     unsigned long long *keys, *sorted;
     int32_t* state;
     unsigned* ctrl;  // per image kCtrlWords: the maximum, then the counters
+    unsigned* tile_max;  // per image: one word per tile of corner_eig_kernel
 };
+inline size_t eig_tiles(int w, int h) { return (size_t)((w + kTileW - 1) / kTileW) * ((h + kTileH - 1) / kTileH); }
 
 CornerBuffers carve_corners(Carver& c, int n_images, int w, int h, int cap) {
     CornerBuffers b;
@@ -659,6 +681,7 @@ CornerBuffers carve_corners(Carver& c, int n_images, int w, int h, int cap) {
     b.sorted = c.take<unsigned long long>(slots);
     b.state = c.take<int32_t>(slots);
     b.ctrl = c.take<unsigned>((size_t)kCtrlWords * n_images);
+    b.tile_max = c.take<unsigned>(eig_tiles(w, h) * n_images);
     static_assert(4 + C_COUNT <= 64, "the counters end before the bucket words");
     return b;
 }
@@ -679,6 +702,7 @@ int run_corners(sfm_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_
     a.info = d_info;
     a.eig = b.eig;
     a.max_bits = b.ctrl;
+    a.tile_max = b.tile_max;
     a.keys = b.keys;
     a.sorted = b.sorted;
     a.rank = b.rank;
@@ -698,6 +722,8 @@ int run_corners(sfm_ctx* ctx, const uint8_t* d_imgs, int n_images, size_t image_
         KernelTimer timer(ctx, KID_CORNER_EIG);
         hipLaunchKernelGGL(corner_eig_kernel, dim3((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH, n), dim3(256), 0,
                            s, a);
+        SFM_HIP_CHECK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(corner_max_kernel, dim3(n), dim3(256), 0, s, a, (int)eig_tiles(w, h));
         SFM_HIP_CHECK(ctx, hipGetLastError());
     }
     {
@@ -857,7 +883,7 @@ int sfm_min_eigen_val_dev(sfm_ctx* ctx, const uint8_t* d_img, int w, int h, size
     a.eig = d_eig;
     a.max_bits = static_cast<unsigned*>(ws);
     a.counters = reinterpret_cast<int32_t*>(ws) + 4;
-    SFM_HIP_CHECK(ctx, hipMemsetAsync(ws, 0, 256, ctx->stream));
+    a.tile_max = nullptr;   // only the response image is wanted
     KernelTimer timer(ctx, KID_CORNER_EIG);
     hipLaunchKernelGGL(corner_eig_kernel, dim3((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH), dim3(256), 0,
                        ctx->stream, a);
