@@ -59,16 +59,16 @@ constexpr int kBlock = 256;
 constexpr int kTileRows = 64;   // train rows per LDS tile (two 32-row MFMA tiles)
 constexpr int kMaxSplits = 16;  // 4 candidates per split and query, 64 per query at most
 
-// l2_pack_kernel and l2_narrow_kernel leave two maxima per workgroup, slots[2 b] and
-// slots[2 b + 1]: over its rows in the group of its first row, and over its rows in later groups
-// (a workgroup across a frame boundary) -- plain stores; an atomic maximum per workgroup on a
+// l2_pack_kernel and l2_narrow_kernel leave two maxima per workgroup, slots[b] and
+// slots[workgroups + b]: over its rows in the group of its first row, and over its rows in later
+// groups (a workgroup across a frame boundary; none when the groups are whole multiples of 32 rows) -- plain stores; an atomic maximum per workgroup on a
 // per-group address costs more than the packing itself (1250 workgroups, all resident at once:
 // 5 to 12 us per launch).  The largest value of group g is the maximum of the first slots of
 // the workgroups that start in g and of the rows of g that sit in the workgroup before them,
 // which are read from the per-row array (fewer than 32).  NaN values are skipped: their rows
 // never rank.
 struct FoldSet {
-    const float* slots;     // [workgroups][2]
+    const float* slots;     // [2][workgroups]
     const float* per_row;   // [rows]
     const int32_t* counts;  // rows in use per group, or null: the others do not count
     float* group;           // [groups]: the result
@@ -157,7 +157,7 @@ __device__ __forceinline__ void fold_group(const FoldArgs& f, int g_all) {
     const long b0 = (first_row + kPackRowsPerBlock - 1) / kPackRowsPerBlock;
     const long b1 = min(blocks, (first_row + p.rows_per_group + kPackRowsPerBlock - 1) / kPackRowsPerBlock);
     float v = 0.f, unused = 0.f;
-    for (long b = b0 + threadIdx.x; b < b1; b += blockDim.x) v = fmaxf(v, p.slots[2 * b]);
+    for (long b = b0 + threadIdx.x; b < b1; b += blockDim.x) v = fmaxf(v, p.slots[b]);
     const long head_end = min(end_row, b0 * kPackRowsPerBlock);
     const long used = p.counts ? p.counts[g] : p.rows_per_group;
     for (long r = first_row + threadIdx.x; r < head_end; r += blockDim.x)
@@ -755,7 +755,7 @@ struct PackSet {
     float* norms;                      // [rows]
     float* acc0;                       // [rows]: -||row||^2 / 2, or null
     const int32_t* counts;             // rows in use per group, or null: the rest does not enter the maxima
-    float* slots;                      // [workgroups of the set][2]
+    float* slots;                      // [2][workgroups of the set]
 };
 struct PackArgs {
     PackSet set[2];
@@ -861,8 +861,8 @@ __global__ __launch_bounds__(kPackBlock) void l2_pack_kernel(PackArgs a) {
     }
     block_max2(largest, largest_later);
     if (threadIdx.x == 0) {
-        p.slots[2 * block] = largest;
-        p.slots[2 * block + 1] = largest_later;
+        p.slots[block] = largest;
+        p.slots[(p.rows + kPackRowsPerBlock - 1) / kPackRowsPerBlock + block] = largest_later;
     }
 }
 
@@ -904,7 +904,7 @@ struct NarrowSet {
     float* acc0;           // [rows], or null
     int rows_per_group;    // as in PackSet
     const int32_t* counts;
-    float* slots;          // [workgroups of the set][2]
+    float* slots;          // [2][workgroups of the set]
 };
 struct NarrowArgs {
     NarrowSet set[2];
@@ -1018,8 +1018,8 @@ __global__ __launch_bounds__(kPackBlock) void l2_narrow_kernel(NarrowArgs a) {
     }
     block_max2(largest, largest_later);
     if (threadIdx.x == 0) {
-        p.slots[2 * block] = largest;
-        p.slots[2 * block + 1] = largest_later;
+        p.slots[block] = largest;
+        p.slots[(p.rows + kPackRowsPerBlock - 1) / kPackRowsPerBlock + block] = largest_later;
     }
 }
 
@@ -1671,8 +1671,10 @@ int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, L2Rows* rows0, cons
     n.global_max = sc.scalars + kScalarGlobalMax;
     if (2L * blocks <= kDirectSlots) {
         for (int i = 0; i < 2; ++i) {
+            // (the second half of a set's slots holds zeros unless a workgroup straddles two groups)
+            const bool straddle = set_groups[i] > 1 && rpg[i] % kPackRowsPerBlock != 0;
             n.norm_slots[i] = rows[i]->norm_slots;
-            n.n_norm_slots[i] = 2 * set_blocks[i];
+            n.n_norm_slots[i] = (straddle ? 2 : 1) * set_blocks[i];
         }
     } else {
         SlotsMaxArgs m{};
