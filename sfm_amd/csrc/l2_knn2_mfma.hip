@@ -934,8 +934,20 @@ __global__ __launch_bounds__(kPackBlock) void l2_narrow_kernel(NarrowArgs a) {
     float m = 0.f, unused = 0.f;
     const bool direct = a.n_norm_slots[0] + a.n_norm_slots[1] > 0;
     if (direct) {
-        for (int i = 0; i < 2; ++i)
-            for (int k = threadIdx.x; k < a.n_norm_slots[i]; k += kPackBlock) m = fmaxf(m, a.norm_slots[i][k]);
+        // eight loads per thread and set go out together (a lane past the end reads the last slot
+        // again); only more than 2048 slots of a set take the loop behind them
+        constexpr int kAtOnce = 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = a.n_norm_slots[i];
+            if (n <= 0) continue;   // workgroup-uniform
+            float t[kAtOnce];
+#pragma unroll
+            for (int u = 0; u < kAtOnce; ++u) t[u] = a.norm_slots[i][min((int)threadIdx.x + u * kPackBlock, n - 1)];
+#pragma unroll
+            for (int u = 0; u < kAtOnce; ++u) m = fmaxf(m, t[u]);
+            for (int k = threadIdx.x + kAtOnce * kPackBlock; k < n; k += kPackBlock) m = fmaxf(m, a.norm_slots[i][k]);
+        }
     } else {
         m = *a.global_max;
     }
