@@ -22,9 +22,12 @@ run() { # name, limit, args...
 }
 
 BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-other-configs --no-sequence --sustain 0 --one-stream"
+# (a chip that has been idle raises its clocks over the first twenty or so launches of a big
+# kernel -- the tracker reads 960 us at first and 845 after 20 steps in one and the same trace --,
+# so the runs are long enough for the averages to be those of the settled clocks)
 for wl in framepair c3 c4 f1 f2 f3 vo; do
     run stats_$wl 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -o $wl \
-        -- $BENCH --workload $wl --steps 5 --warmup 2
+        -- $BENCH --workload $wl --steps 100 --warmup 50
 done
 run stats_c5 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c5" -o c5 \
     -- $BENCH --workload c5 --frames 96 --steps 3 --warmup 1
