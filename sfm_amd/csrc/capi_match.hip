@@ -357,10 +357,15 @@ int sfm_match_pairs_dev(sfm_ctx* ctx, int norm, const void* d_desc, int n_frames
     }
     if (!d_desc || !d_pairs || (cap > 0 && !d_matches))
         return set_error(ctx, SFM_E_INVALID, "NULL pointer argument");
-    if (norm != SFM_NORM_HAMMING)
+    if (norm != SFM_NORM_HAMMING) {
+        // SFM_L2_PAIR_CHUNK=<pairs>: a testing aid (read per call) that cuts the pair list into
+        // smaller pieces than the workspace needs, to run the many-pieces path on few pairs
+        int chunk = kL2PairChunk;
+        if (const char* e = getenv("SFM_L2_PAIR_CHUNK")) chunk = std::max(1, std::min(atoi(e), kL2PairChunk));
         return l2_match_frames_dev(ctx, norm == SFM_NORM_L2SQR, static_cast<const float*>(d_desc),
                                    n_frames, frame_stride, rows_per_frame, d_counts, d, d_pairs,
-                                   n_pairs, ratio, d_matches, cap, d_match_counts, kL2PairChunk);
+                                   n_pairs, ratio, d_matches, cap, d_match_counts, chunk);
+    }
     if (frame_stride < (size_t)rows_per_frame * d)
         return set_error(ctx, SFM_E_INVALID, "frame stride smaller than a frame");
 

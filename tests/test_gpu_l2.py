@@ -379,6 +379,42 @@ def test_l2_match_pairs_many_rows(ctx, oracle):
         assert _tuples(m[p][: mc[p]]) == _tuples(want), (i, j)
 
 
+@pytest.mark.parametrize("exhaustive", [False, True])
+def test_l2_match_pairs_in_pieces(ctx, oracle, monkeypatch, exhaustive):
+    """The pair list cut into pieces of three (SFM_L2_PAIR_CHUNK): the frames are packed once, the
+    passes run once per piece; with SFM_L2_EXHAUSTIVE every query of every piece also goes through
+    the exhaustive pass, whose counters are handed from piece to piece."""
+    import torch
+
+    from sfm_amd import capi
+
+    monkeypatch.setenv("SFM_L2_PAIR_CHUNK", "3")
+    if exhaustive:
+        monkeypatch.setenv("SFM_L2_EXHAUSTIVE", "1")
+    rng = np.random.default_rng(23)
+    n_frames, rows, dim = 5, 300, 128
+    counts = np.array([300, 257, 64, 299, 120], np.int32)
+    base = rng.standard_normal((rows, dim)).astype(np.float32)
+    stack = np.stack([base[rng.permutation(rows)] + 0.2 * rng.standard_normal((rows, dim)).astype(np.float32)
+                      for _ in range(n_frames)])
+    pairs = np.array([(i, j) for i in range(n_frames) for j in range(n_frames) if i != j][:11], np.int32)
+    dev = torch.device("cuda:0")
+    d_desc = torch.from_numpy(stack).to(dev)
+    d_counts, d_pairs = torch.from_numpy(counts).to(dev), torch.from_numpy(pairs).to(dev)
+    d_matches = torch.zeros((len(pairs), rows, 4), dtype=torch.int32, device=dev)
+    d_mc = torch.zeros(len(pairs), dtype=torch.int32, device=dev)
+    for _ in range(2):   # a second call finds the counters as the first one left them
+        ctx.match_pairs_dev(capi.NORM_L2, d_desc, n_frames, rows * dim * 4, rows, d_counts, dim, d_pairs,
+                            len(pairs), 0.8, d_matches, rows, d_mc)
+        ctx.synchronize()
+        mc = d_mc.cpu().numpy()
+        m = d_matches.cpu().numpy().view(capi.DMATCH_DTYPE).reshape(len(pairs), rows)
+        for p, (i, j) in enumerate(pairs):
+            want = oracle.robust_matches(oracle.NORM_L2, stack[i][: counts[i]], stack[j][: counts[j]], 0.8)
+            assert mc[p] == len(want), (i, j)
+            assert _tuples(m[p][: mc[p]]) == _tuples(want), (i, j)
+
+
 @pytest.mark.parametrize("integer", [True, False])
 def test_l2_full_size_20000x20000x128(ctx, oracle, integer):
     """The float-matching configuration at the size it is quoted on (20 000 x 20 000 x 128, both
