@@ -58,6 +58,11 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int kBlock = 256;
 constexpr int kTileRows = 64;   // train rows per LDS tile (two 32-row MFMA tiles)
 constexpr int kMaxSplits = 16;  // 4 candidates per split and query, 64 per query at most
+// The narrow candidate kernel joins the running lists once per kMergeTiles tiles: a key carries
+// its position among the 32 kMergeTiles accumulators of that stretch in its low mantissa bits.
+constexpr int kMergeTiles = 4;
+constexpr int kNarrowTagBits = 7;
+static_assert((32 * kMergeTiles) == (1 << kNarrowTagBits) && kMergeTiles % 2 == 0, "tag = tile of the stretch, position in the tile");
 
 // l2_pack_kernel and l2_narrow_kernel leave two maxima per workgroup, slots[b] and
 // slots[workgroups + b]: over its rows in the group of its first row, and over its rows in later
@@ -551,32 +556,47 @@ void l2_candidates_narrow_kernel(L2Args a) {
             for (int r = 0; r < 16; ++r) accA[mt][n][r] = accB[mt][n][r] = kNoRowAcc;
 
     // The fold of a finished tile.  A lane holds 32 accumulators of each of its query columns;
-    // the five low mantissa bits of one are replaced by its position among them (a change
-    // below 2^-18 of its size, which the error bound of the re-score pass covers), so that the
-    // three largest of the tile fall out of one maximum and two medians each with no train
-    // index carried along -- the tagged values of a tile are all different.  Only the largest
-    // two then enter the running lists, as keys, with the train row their tags name.
+    // the kNarrowTagBits low mantissa bits of one are replaced by a tag (a change below
+    // 2^(kNarrowTagBits - 23) of its size, which the error bound of the re-score pass covers):
+    // its position in the tile in the five low bits (an inline constant of the instruction),
+    // zero above.  The three largest of a stretch of kMergeTiles tiles fall out of one maximum
+    // and two medians each with no train index carried along: before the next tile of the
+    // stretch is folded, 32 is added to the bit patterns of the three (age_tops: the upper tag
+    // bits count the tiles folded since, the order of the three stays), so the tagged values
+    // of a stretch are all different.  Only the largest two then enter the running lists, once
+    // per stretch, as keys, with the train row their tags name.
+    constexpr unsigned kTagMask = (1u << kNarrowTagBits) - 1u;
     float top0[NT], top1[NT], top2[NT];
     auto fold_key = [&](const floatx16 (&acc)[2][NT], int kq) {
         const int gi = kq / 4, r = kq % 4;
         const int mt = gi / (NT * 4), n = (gi / 4) % NT, gq = gi % 4;
         const unsigned tag = 16 * mt + 4 * gq + r;
         const float v =
-            __uint_as_float((__float_as_uint(acc[mt][n][4 * gq + r]) & ~31u) | tag);
+            __uint_as_float((__float_as_uint(acc[mt][n][4 * gq + r]) & ~kTagMask) | tag);
         asm("v_med3_f32 %0, %0, %1, %2" : "+v"(top2[n]) : "v"(v), "v"(top1[n]));
         asm("v_med3_f32 %0, %0, %1, %2" : "+v"(top1[n]) : "v"(v), "v"(top0[n]));
         asm("v_max_f32 %0, %0, %1" : "+v"(top0[n]) : "v"(v));
     };
-    // which = 0, 1: the largest, second-largest accumulator of the tile enters the lists of
-    // column n as a key (strict comparisons: of equal keys the earlier tile stays ahead);
-    // which = 2: the third only moves the third-smallest key seen.
+    // (after the first tile of a stretch the three are finite: masked rows rank as kNoRowAcc)
+    auto age_tops = [&]() {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            top0[n] = __uint_as_float(__float_as_uint(top0[n]) + 32u);
+            top1[n] = __uint_as_float(__float_as_uint(top1[n]) + 32u);
+            top2[n] = __uint_as_float(__float_as_uint(top2[n]) + 32u);
+        }
+    };
+    // which = 0, 1: the largest, second-largest accumulator of the stretch whose last folded
+    // tile starts at train row tbase enters the lists of column n as a key (strict
+    // comparisons: of equal keys the earlier stretch stays ahead); which = 2: the third only
+    // moves the third-smallest key seen.
     auto merge = [&](int n, int which, int tbase) {
         const float v = which == 0 ? top0[n] : which == 1 ? top1[n] : top2[n];
         const float key = -2.f * v;   // exact
         asm("v_med3_f32 %0, %0, %1, %2" : "+v"(third[n]) : "v"(key), "v"(best1[n]));
         if (which == 2) return;
         const unsigned tag = __float_as_uint(v);
-        const int ti = tbase + 4 * lh + (int)(((tag & 28u) << 1) | (tag & 3u));
+        const int ti = tbase + 4 * lh + (int)(((tag & 28u) << 1) | (tag & 3u)) - (int)((tag & (kTagMask & ~31u)) << 1);
         const unsigned long long c0 = __builtin_amdgcn_ballot_w64(key < best0[n]);
         const unsigned long long c1 = __builtin_amdgcn_ballot_w64(key < best1[n]);
         const float t = select_f(c1, key, best1[n]);
@@ -593,9 +613,14 @@ void l2_candidates_narrow_kernel(L2Args a) {
 
     constexpr int kKeys = 2 * NT * 16;             // keys of a finished tile per lane
     constexpr int kMfmas = kSteps * 2 * NT * kTerms;   // MFMAs of a tile per wave
-    constexpr int kFoldUnits = kMfmas - 3 * NT;    // the last 3 NT carry the merges
-    static_assert(kFoldUnits > 0, "the fold needs room beside the merges");
-    auto tile_step = [&](floatx16 (&accC)[2][NT], const floatx16 (&accF)[2][NT], int k) {
+    static_assert(kMfmas > 3 * NT, "the fold needs room beside the merges");
+    // tile k, the P-th of its stretch: its MFMAs, and underneath them the fold of tile k - 1;
+    // the first tile of a stretch carries the merges of the stretch before it in its last
+    // 3 NT units
+    auto tile_step = [&](floatx16 (&accC)[2][NT], const floatx16 (&accF)[2][NT], int k, auto phase) {
+        constexpr int P = decltype(phase)::value;
+        constexpr int PF = (P + kMergeTiles - 1) % kMergeTiles;   // place of the folded tile
+        constexpr int kFoldUnits = P == 0 ? kMfmas - 3 * NT : kMfmas;
         const int group = k / kGroup, sub = k % kGroup, buf = group & 1;
         if (sub == 0 && (group + 1) * kGroup < ntiles) stage(group + 1, buf ^ 1);
         const float* tile = lds + (buf * kGroup + sub) * kTileFloats;
@@ -633,7 +658,8 @@ void l2_candidates_narrow_kernel(L2Args a) {
         load_a(0, ah, al);
         // the fold of the finished tile is dealt over the MFMAs of this one, in a pinned order
         // (see the fp32 kernel)
-        reset_tops();
+        if (PF == 0) reset_tops();
+        else age_tops();
         int unit = 0;
 #pragma unroll
         for (int s = 0; s < kSteps; ++s) {
@@ -668,17 +694,23 @@ void l2_candidates_narrow_kernel(L2Args a) {
         if (sub == kGroup - 1) __syncthreads();   // (past the last tile nothing is read)
     };
 
-    for (int k = 0; k < ntiles; k += 2) {
-        tile_step(accA, accB, k);
-        if (k + 1 < ntiles) tile_step(accB, accA, k + 1);
+    static_assert(kMergeTiles == 4, "the stretch is written out below");
+    reset_tops();   // (the first tile folds the start values: nothing enters)
+    for (int k = 0; k < ntiles; k += kMergeTiles) {
+        tile_step(accA, accB, k, std::integral_constant<int, 0>());
+        if (k + 1 < ntiles) tile_step(accB, accA, k + 1, std::integral_constant<int, 1>());
+        if (k + 2 < ntiles) tile_step(accA, accB, k + 2, std::integral_constant<int, 2>());
+        if (k + 3 < ntiles) tile_step(accB, accA, k + 3, std::integral_constant<int, 3>());
     }
-    {
+    if (ntiles > 0) {
+        // the last tile, and the stretch it ends
         const int tbase_last = t_begin + (ntiles - 1) * kTileRows;
-        reset_tops();
+        if ((ntiles - 1) % kMergeTiles == 0) reset_tops();
+        else age_tops();
         if (ntiles & 1) {
 #pragma unroll
             for (int kq = 0; kq < kKeys; ++kq) fold_key(accA, kq);
-        } else if (ntiles > 0) {
+        } else {
 #pragma unroll
             for (int kq = 0; kq < kKeys; ++kq) fold_key(accB, kq);
         }
@@ -1771,14 +1803,15 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int sq
     // Per pass: roundings of the norms, of the accumulation steps (fp32: K, fp16: K exact
     // products, bfloat16: 3 K) and of the sequential sum, counted four per product.  bfloat16:
     // 4 * 2^-16 of the norms left out by the split.  Narrow passes: the position tag in a key's
-    // five low bits (below 2^-18 of a key that is at most twice the norms: 2^-17, counted as
-    // 2^-16).  Every pass: the lane number in the six low bits of a key when the re-score pass
-    // ranks the candidates (2^-16 of the norms).  The fp16 pass adds its measured rounding of
-    // the rows per query (l2_rescore_kernel).
+    // kNarrowTagBits low bits (below 2^(kNarrowTagBits - 23) of a key that is at most twice the
+    // norms: 2^-15 for seven bits, counted as 2^-14).  Every pass: the lane number in the six low
+    // bits of a key when the re-score pass ranks the candidates (2^-16 of the norms).  The fp16
+    // pass adds its measured rounding of the rows per query (l2_rescore_kernel).
     const double eps = (double)FLT_EPSILON, tag = 1.0 / 65536.0;
+    const double narrow_tag = (double)(1 << (kNarrowTagBits - 5)) * tag;
     r.key_error = mode == kL2F32   ? (4.0 * plan.K + 64.0) * eps + tag
-                  : mode == kL2F16 ? (4.0 * plan.K + 64.0) * eps + 2.0 * tag
-                                   : (12.0 * plan.K + 64.0) * eps + 6.0 * tag;
+                  : mode == kL2F16 ? (4.0 * plan.K + 64.0) * eps + tag + narrow_tag
+                                   : (12.0 * plan.K + 64.0) * eps + 5.0 * tag + narrow_tag;
     r.force_exhaustive = l2_force_exhaustive() ? 1 : 0;
     r.knn_idx = s.knn_idx;
     r.knn_dist = s.knn_dist;
