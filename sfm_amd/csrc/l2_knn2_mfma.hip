@@ -60,9 +60,10 @@ constexpr int kTileRows = 64;   // train rows per LDS tile (two 32-row MFMA tile
 constexpr int kMaxSplits = 16;  // 4 candidates per split and query, 64 per query at most
 // The narrow candidate kernel joins the running lists once per kMergeTiles tiles: a key carries
 // its position among the 32 kMergeTiles accumulators of that stretch in its low mantissa bits.
+// (Eight tiles and eight tag bits measured no faster than four and seven.)
 constexpr int kMergeTiles = 4;
 constexpr int kNarrowTagBits = 7;
-static_assert((32 * kMergeTiles) == (1 << kNarrowTagBits) && kMergeTiles % 2 == 0, "tag = tile of the stretch, position in the tile");
+static_assert((32 * kMergeTiles) == (1 << kNarrowTagBits), "tag = tiles folded since, position in the tile");
 
 // l2_pack_kernel and l2_narrow_kernel leave two maxima per workgroup, slots[b] and
 // slots[workgroups + b]: over its rows in the group of its first row, and over its rows in later
@@ -694,13 +695,20 @@ void l2_candidates_narrow_kernel(L2Args a) {
         if (sub == kGroup - 1) __syncthreads();   // (past the last tile nothing is read)
     };
 
-    static_assert(kMergeTiles == 4, "the stretch is written out below");
     reset_tops();   // (the first tile folds the start values: nothing enters)
+    // the tiles of a stretch, each with its place as a constant; the accumulator sets alternate
+    auto stretch = [&](int k, auto... place) {
+        ((k + decltype(place)::value < ntiles
+              ? (decltype(place)::value & 1 ? tile_step(accB, accA, k + decltype(place)::value, place)
+                                            : tile_step(accA, accB, k + decltype(place)::value, place),
+                 0)
+              : 0),
+         ...);
+    };
     for (int k = 0; k < ntiles; k += kMergeTiles) {
-        tile_step(accA, accB, k, std::integral_constant<int, 0>());
-        if (k + 1 < ntiles) tile_step(accB, accA, k + 1, std::integral_constant<int, 1>());
-        if (k + 2 < ntiles) tile_step(accA, accB, k + 2, std::integral_constant<int, 2>());
-        if (k + 3 < ntiles) tile_step(accB, accA, k + 3, std::integral_constant<int, 3>());
+        static_assert(kMergeTiles == 4, "one constant per tile of the stretch");
+        stretch(k, std::integral_constant<int, 0>(), std::integral_constant<int, 1>(),
+                std::integral_constant<int, 2>(), std::integral_constant<int, 3>());
     }
     if (ntiles > 0) {
         // the last tile, and the stretch it ends

@@ -88,6 +88,46 @@ def test_l2_tiny_and_empty(ctx, oracle):
         ctx.knn2(capi.NORM_L2, np.zeros((4, 300), np.float32), np.zeros((4, 300), np.float32))
 
 
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+@pytest.mark.parametrize("nt", [10277, 12288, 4100])
+def test_l2_neighbours_planted_across_tiles(ctx, oracle, monkeypatch, nt, mode):
+    """The narrow candidate passes keep the three best keys of a stretch of four 64-row tiles
+    and join the running lists once per stretch.  Every query gets its three nearest train rows
+    planted a chosen number of rows apart -- in one tile, in neighbouring tiles of a stretch, in
+    different stretches, across the ranges of two workgroups, at the end of the set -- and the
+    result must be the oracle's with (nearly) no query sent to the exhaustive pass."""
+    from sfm_amd import capi
+
+    monkeypatch.setenv("SFM_L2_MFMA", mode)
+    rng = np.random.default_rng(nt)
+    nq, dim = 600, 128
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    t = rng.standard_normal((nt, dim)).astype(np.float32)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    gaps = [1, 3, 4, 8, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 256, 257, 448, 640, 1500]
+    used = set()
+    for i in range(nq):
+        gap = gaps[i % len(gaps)]
+        for _ in range(1000):
+            base = int(rng.integers(0, nt - 2 * gap))
+            if i in (0, 7, 14):        # three of them at the very end of the set
+                base = nt - 1 - 2 * gap - {0: 0, 7: 5, 14: 11}[i]
+            order = rng.permutation(3)     # which of the three rows is nearest
+            rows = [base + int(o) * gap for o in order]
+            if not used.intersection(rows):
+                break
+        used.update(rows)
+        for rank, row in enumerate(rows):
+            noise = rng.standard_normal(dim).astype(np.float32)
+            t[row] = q[i] + np.float32(0.02 * (rank + 1)) * noise / np.linalg.norm(noise)
+    idx, dist = ctx.knn2(capi.NORM_L2SQR, q, t)
+    oidx, odist = oracle.knn2_l2(q, t, squared=True)
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_array_equal(dist, odist)
+    assert ctx.l2_exhaustive_count() <= 3
+
+
 @pytest.mark.parametrize("norm_name,ratio", [("L2", 0.7), ("L2SQR", 0.5)])
 @pytest.mark.parametrize("integer", [True, False])
 def test_l2_robust_matches_vs_oracle(ctx, oracle, norm_name, ratio, integer):
