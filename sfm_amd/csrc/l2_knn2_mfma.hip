@@ -523,19 +523,46 @@ void l2_candidates_narrow_kernel(L2Args a) {
     const int t_end = min(nt, t_begin + chunk);
     const int ntiles = t_end > t_begin ? (t_end - t_begin + kTileRows - 1) / kTileRows : 0;
 
-    // group g of kGroup tiles into buffer buf
+    // group g of kGroup tiles into buffer buf.  A lane's chunk sits at the same place of every
+    // tile: while the tile lies inside the set its address is a wave-uniform base, advanced by
+    // the scalar unit, plus a byte offset that costs one instruction -- staging instruction i
+    // covers rows i R .. i R + R - 1 (R = 64 / chunks per row), so the row of a lane is
+    // i R + lane / chunks, its swizzle term (i R & kSwizzle) | lane / chunks, and its offset
+    // lane_off ^ 16 (i R & kSwizzle) beyond the instruction's first row.  Only a tile that
+    // reaches past the last row forms its addresses per lane (rows past the end read the last
+    // row and are masked by a start value of kNoRowAcc).
+    constexpr int kStageInstrs = kGroup * kChunksPerRow / WAVES;
+    constexpr int kRowsPerInstr = 64 / kChunksPerRow;
+    static_assert(kGroup == 1 && 64 % kChunksPerRow == 0 && kRowsPerInstr - 1 <= kSwizzle, "the offset formula");
+    const uint32_t lane_off = (uint32_t)((((lane % kChunksPerRow) ^ (lane / kChunksPerRow)) * 16) |
+                                         ((lane / kChunksPerRow) * (kRowFloats * 4)));
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // (in a scalar register)
     auto stage = [&](int g, int buf) {
         const int tbase = t_begin + g * kGroup * kTileRows;
         float* dst = lds + buf * kGroup * kTileFloats;
+        if (tbase + kGroup * kTileRows <= nt) {
+            // (formed here, from one register: offsets kept across the loop would be spilled)
+            uint32_t lo = lane_off;
+            asm volatile("" : "+v"(lo));
 #pragma unroll
-        for (int it = 0; it < kGroup * kChunksPerRow / WAVES; ++it) {
-            const int instr = wave * (kGroup * kChunksPerRow / WAVES) + it;
-            const int p = instr * 64 + lane;
-            const int row = p / kChunksPerRow, cpos = p % kChunksPerRow;
-            const int c = cpos ^ (row & kSwizzle);
-            int trow = tbase + row;
-            trow = trow < nt ? trow : nt - 1;  // clamped rows are masked by a norm of kNoRow
-            glds16(trows + (size_t)trow * kRowFloats + c * 4, dst + instr * 256);
+            for (int it = 0; it < kStageInstrs; ++it) {
+                const int instr = wave_u * kStageInstrs + it;
+                const char* base = reinterpret_cast<const char*>(
+                    trows + ((size_t)tbase + (size_t)(instr * kRowsPerInstr)) * kRowFloats);
+                const uint32_t off = lo ^ (uint32_t)(((instr * kRowsPerInstr) & kSwizzle) * 16);
+                glds16(base + off, dst + instr * 256);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < kStageInstrs; ++it) {
+                const int instr = wave_u * kStageInstrs + it;
+                const int p = instr * 64 + lane;
+                const int row = p / kChunksPerRow, cpos = p % kChunksPerRow;
+                const int c = cpos ^ (row & kSwizzle);
+                int trow = tbase + row;
+                trow = trow < nt ? trow : nt - 1;
+                glds16(trows + (size_t)trow * kRowFloats + c * 4, dst + instr * 256);
+            }
         }
         if (tid < kGroup * kTileRows) {
             const int trow = tbase + tid;
