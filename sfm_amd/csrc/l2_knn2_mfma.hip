@@ -594,24 +594,43 @@ void l2_candidates_narrow_kernel(L2Args a) {
     // of a stretch are all different.  Only the largest two then enter the running lists, once
     // per stretch, as keys, with the train row their tags name.
     constexpr unsigned kTagMask = (1u << kNarrowTagBits) - 1u;
-    float top0[NT], top1[NT], top2[NT];
-    auto fold_key = [&](const floatx16 (&acc)[2][NT], int kq) {
+    float top0[NT], top1[NT];
+    auto tagged = [&](const floatx16 (&acc)[2][NT], int kq) {
         const int gi = kq / 4, r = kq % 4;
         const int mt = gi / (NT * 4), n = (gi / 4) % NT, gq = gi % 4;
         const unsigned tag = 16 * mt + 4 * gq + r;
-        const float v =
-            __uint_as_float((__float_as_uint(acc[mt][n][4 * gq + r]) & ~kTagMask) | tag);
-        asm("v_med3_f32 %0, %0, %1, %2" : "+v"(top2[n]) : "v"(v), "v"(top1[n]));
-        asm("v_med3_f32 %0, %0, %1, %2" : "+v"(top1[n]) : "v"(v), "v"(top0[n]));
-        asm("v_max_f32 %0, %0, %1" : "+v"(top0[n]) : "v"(v));
+        return __uint_as_float((__float_as_uint(acc[mt][n][4 * gq + r]) & ~kTagMask) | tag);
     };
-    // (after the first tile of a stretch the three are finite: masked rows rank as kNoRowAcc)
+    // Keys 2 p and 2 p + 1 (one query column).  With t0 >= t1 the largest two so far, the
+    // second largest of {t0, t1, x, y} is max(t1, median(t0, x, y)); pairs come in twos (the
+    // four keys of one register group), and the two updates of t1 are one maximum of three:
+    // five instructions per four keys.  That maximum is issued with the next group's first
+    // pair, two instructions behind the median it reads (the compiler puts a wait state
+    // between an asm statement and a reader right behind it).
+    float mid_a[NT], mid_b[NT];
+    auto fold_pair = [&](const floatx16 (&acc)[2][NT], int p, int last) {
+        const int n = (p / 8) % NT;
+        const float x = tagged(acc, 2 * p), y = tagged(acc, 2 * p + 1);
+        if ((p & 1) == 0) {
+            if (p > 0) {
+                const int m = ((p - 1) / 8) % NT;
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(top1[m]) : "v"(mid_a[m]), "v"(mid_b[m]));
+            }
+            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(mid_a[n]) : "v"(top0[n]), "v"(x), "v"(y));
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(top0[n]) : "v"(x), "v"(y));
+        } else {
+            asm("v_med3_f32 %0, %1, %2, %3" : "=v"(mid_b[n]) : "v"(top0[n]), "v"(x), "v"(y));
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(top0[n]) : "v"(x), "v"(y));
+            if (p == last)
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(top1[n]) : "v"(mid_a[n]), "v"(mid_b[n]));
+        }
+    };
+    // (after the first tile of a stretch the two are finite: masked rows rank as kNoRowAcc)
     auto age_tops = [&]() {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             top0[n] = __uint_as_float(__float_as_uint(top0[n]) + 32u);
             top1[n] = __uint_as_float(__float_as_uint(top1[n]) + 32u);
-            top2[n] = __uint_as_float(__float_as_uint(top2[n]) + 32u);
         }
     };
     // which = 0, 1: the largest, second-largest accumulator of the stretch whose last folded
@@ -619,10 +638,9 @@ void l2_candidates_narrow_kernel(L2Args a) {
     // comparisons: of equal keys the earlier stretch stays ahead); which = 2: the third only
     // moves the third-smallest key seen.
     auto merge = [&](int n, int which, int tbase) {
-        const float v = which == 0 ? top0[n] : which == 1 ? top1[n] : top2[n];
+        const float v = which == 0 ? top0[n] : top1[n];
         const float key = -2.f * v;   // exact
         asm("v_med3_f32 %0, %0, %1, %2" : "+v"(third[n]) : "v"(key), "v"(best1[n]));
-        if (which == 2) return;
         const unsigned tag = __float_as_uint(v);
         const int ti = tbase + 4 * lh + (int)(((tag & 28u) << 1) | (tag & 3u)) - (int)((tag & (kTagMask & ~31u)) << 1);
         const unsigned long long c0 = __builtin_amdgcn_ballot_w64(key < best0[n]);
@@ -636,19 +654,19 @@ void l2_candidates_narrow_kernel(L2Args a) {
     };
     auto reset_tops = [&]() {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) top0[n] = top1[n] = top2[n] = -INFINITY;
+        for (int n = 0; n < NT; ++n) top0[n] = top1[n] = -INFINITY;
     };
 
-    constexpr int kKeys = 2 * NT * 16;             // keys of a finished tile per lane
+    constexpr int kPairs = NT * 16;                // pairs of keys of a finished tile per lane
     constexpr int kMfmas = kSteps * 2 * NT * kTerms;   // MFMAs of a tile per wave
-    static_assert(kMfmas > 3 * NT, "the fold needs room beside the merges");
+    static_assert(kMfmas > 2 * NT, "the fold needs room beside the merges");
     // tile k, the P-th of its stretch: its MFMAs, and underneath them the fold of tile k - 1;
     // the first tile of a stretch carries the merges of the stretch before it in its last
     // 3 NT units
     auto tile_step = [&](floatx16 (&accC)[2][NT], const floatx16 (&accF)[2][NT], int k, auto phase) {
         constexpr int P = decltype(phase)::value;
         constexpr int PF = (P + kMergeTiles - 1) % kMergeTiles;   // place of the folded tile
-        constexpr int kFoldUnits = P == 0 ? kMfmas - 3 * NT : kMfmas;
+        constexpr int kFoldUnits = P == 0 ? kMfmas - 2 * NT : kMfmas;
         const int group = k / kGroup, sub = k % kGroup, buf = group & 1;
         if (sub == 0 && (group + 1) * kGroup < ntiles) stage(group + 1, buf ^ 1);
         const float* tile = lds + (buf * kGroup + sub) * kTileFloats;
@@ -705,10 +723,10 @@ void l2_candidates_narrow_kernel(L2Args a) {
                         accC[mt][n] = narrow_mfma(av, bv, accC[mt][n]);
                         if (unit < kFoldUnits) {
 #pragma unroll
-                            for (int kq = (unit * kKeys) / kFoldUnits; kq < ((unit + 1) * kKeys) / kFoldUnits; ++kq)
-                                fold_key(accF, kq);
+                            for (int p = (unit * kPairs) / kFoldUnits; p < ((unit + 1) * kPairs) / kFoldUnits; ++p)
+                                fold_pair(accF, p, kPairs - 1);
                         } else {
-                            merge((unit - kFoldUnits) / 3, (unit - kFoldUnits) % 3, tbase_prev);
+                            merge((unit - kFoldUnits) / 2, (unit - kFoldUnits) % 2, tbase_prev);
                         }
                         ++unit;
                         __builtin_amdgcn_sched_barrier(0);
@@ -744,13 +762,13 @@ void l2_candidates_narrow_kernel(L2Args a) {
         else age_tops();
         if (ntiles & 1) {
 #pragma unroll
-            for (int kq = 0; kq < kKeys; ++kq) fold_key(accA, kq);
+            for (int p = 0; p < kPairs; ++p) fold_pair(accA, p, kPairs - 1);
         } else {
 #pragma unroll
-            for (int kq = 0; kq < kKeys; ++kq) fold_key(accB, kq);
+            for (int p = 0; p < kPairs; ++p) fold_pair(accB, p, kPairs - 1);
         }
 #pragma unroll
-        for (int u = 0; u < 3 * NT; ++u) merge(u / 3, u % 3, tbase_last);
+        for (int u = 0; u < 2 * NT; ++u) merge(u / 2, u % 2, tbase_last);
     }
 
     const float unscale = F16 ? a.narrow_scale[1] : 1.f;   // 1 / s^2
@@ -1116,6 +1134,12 @@ struct RescoreArgs {
     const int32_t* cand;
     const float* cand_key;
     const float* cand_third;
+    // Narrow candidate passes: train rows per stretch (kMergeTiles tiles).  A list then holds the
+    // best two of every stretch of its rows, and cand_third the third-smallest key among those
+    // pairs: the other rows of a stretch rank behind its second, which is behind that key unless
+    // the stretch gave the list both its entries -- l2_rescore_kernel scores such a stretch row
+    // by row when its second is too near.  0: cand_third bounds every other row of the list.
+    int stretch_rows;
     const float* q_norms;  // ||q||^2 per packed row, rows_cap per frame
     const float* t_norm_max;  // per train frame: the largest ||t||^2 of its rows in use
     double key_error;  // bound on |ranking key + ||q||^2 - sequential distance| / (||q||^2 + max ||t||^2)
@@ -1208,17 +1232,18 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
     // holds it: all different, so the smallest kRescored are well defined, and within 2^-17 of
     // the key (the error bound of the proof allows for it).
     int ti = -1;
-    unsigned pre = 0xFFFFFFFFu;
+    unsigned pre = 0xFFFFFFFFu, held_key = 0xFFFFFFFFu;
     if (lane < ncand) {
         const int split = lane >> 2, slot = lane & 3;
         const size_t o = ((((size_t)problem * a.splits + split) * a.rows_cap) + q) * 4 + slot;
         ti = a.cand[o];
         if (ti >= 0) {
             const unsigned u = __float_as_uint(a.cand_key[o]);
-            const unsigned ord = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-            pre = (ord & ~63u) | (unsigned)lane;
+            held_key = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+            pre = (held_key & ~63u) | (unsigned)lane;
         }
     }
+    const int held = ti;   // (the list entry this lane holds, re-scored or not)
     bool chosen = ncand <= kRescored;
     unsigned ninth = 0xFFFFFFFFu;  // smallest key among the candidates not re-scored
     if (!chosen) {
@@ -1235,14 +1260,33 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
         ninth = wave_min_u32(rest);
     }
     if (!chosen) ti = -1;
-    // T: no train row outside the re-scored set has a smaller ranking key (orderable form)
+    // T: no train row outside the re-scored set has a smaller ranking key (orderable form).
+    // Lane 2 split + half looks at the list of that split and lane half: the key cand_third
+    // bounds, and -- narrow passes -- whether both entries came from one stretch of the list's
+    // rows (same_stretch: the stretch's first row; second_key: the key the stretch's other
+    // rows cannot be below).
     unsigned others = ninth;
+    int same_stretch = -1;
+    unsigned second_key = 0xFFFFFFFFu;
+    const int nt_rows = a.counts ? a.counts[tf] : a.nt_uniform;
+    const int split_rows = (nt_rows + a.splits - 1) / a.splits;
     if (lane < 2 * a.splits) {
         const int split = lane >> 1, half = lane & 1;
-        const float k3 = a.cand_third[((((size_t)problem * a.splits + split) * a.rows_cap) + q) * 2 + half];
+        const size_t o = (((size_t)problem * a.splits + split) * a.rows_cap) + q;
+        const float k3 = a.cand_third[o * 2 + half];
         const unsigned u = __float_as_uint(k3);
         const unsigned ord = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
         others = ord < others ? ord : others;
+    }
+    if (a.stretch_rows > 0) {   // the list's entries sit in lanes 2 l and 2 l + 1
+        const int i0 = __shfl(held, (2 * lane) & 63), i1 = __shfl(held, (2 * lane + 1) & 63);
+        const unsigned key1 = __shfl(held_key, (2 * lane + 1) & 63);
+        const int first = (lane >> 1) * split_rows;
+        if (lane < 2 * a.splits && i0 >= 0 && i1 >= 0 &&
+            (i0 - first) / a.stretch_rows == (i1 - first) / a.stretch_rows) {
+            same_stretch = first + (i0 - first) / a.stretch_rows * a.stretch_rows;
+            second_key = key1;
+        }
     }
     others = wave_min_u32(others);
     // the rows to re-score, dealt to lanes 0 .. kRescored - 1 in lane order of their holders
@@ -1291,8 +1335,8 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
         if (!a.squared) d = sqrtf(d);  // batchDistL2_32f
         key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)mine;
     }
-    const unsigned long long k0 = wave_min_u64(key);
-    const unsigned long long k1 = wave_min_u64(key == k0 ? ~0ull : key);
+    unsigned long long k0 = wave_min_u64(key);
+    unsigned long long k1 = wave_min_u64(key == k0 ? ~0ull : key);
     // Proof that no other row can reach the second place: its sequential squared distance is
     // at least its ranking key + ||q||^2 - E >= T + ||q||^2 - E.  E bounds the rounding of the
     // norms (pairwise sums), of the K accumulation steps of the matrix pipe (each at most one
@@ -1301,13 +1345,11 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
     // factor (4 K + 64) eps is more than twice their total.  The bfloat16 candidate pass has
     // three times the accumulation steps and leaves out 4 * 2^-16 of the norms (see there).
     bool proven = true;
-    if (others != 0xFFFFFFFFu) {   // there are train rows outside the re-scored set
+    const bool listed = others != 0xFFFFFFFFu || __builtin_amdgcn_ballot_w64(same_stretch >= 0) != 0;
+    if (listed) {   // there are train rows outside the re-scored set
         if (k1 == ~0ull) {
             proven = false;
         } else {
-            const unsigned ord = others;
-            const unsigned u = ord ^ ((ord >> 31) ? 0x80000000u : 0xFFFFFFFFu);
-            const double T = (double)__uint_as_float(u);
             const double qn = (double)a.q_norms[(size_t)qf * a.rows_cap + q];
             const double tmax = (double)a.t_norm_max[tf];
             double E = a.key_error * (qn + tmax);
@@ -1317,11 +1359,82 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
                 const double rq = (double)a.q_res[(size_t)qf * a.rows_cap + q], rt = (double)a.t_res_max[tf];
                 E += 2.002 * (rq * sqrt(tmax) + sqrt(qn) * rt + rq * rt);
             }
-            // NORM_L2 ranks by the rounded square root, which maps neighbouring sums to one
-            // value: a row ties or wins only if its sum is below the square of the next float
-            const float d1 = __uint_as_float((unsigned)(k1 >> 32));
-            const double d1n = (double)nextafterf(d1, INFINITY);
-            proven = T + qn - E > (a.squared ? (double)d1 : d1n * d1n);
+            // no row whose ranking key is at least the key of orderable form ord reaches the
+            // second place.  NORM_L2 ranks by the rounded square root, which maps neighbouring
+            // sums to one value: a row ties or wins only if its sum is below the square of the
+            // next float
+            auto out_of_reach = [&](unsigned ord) {
+                const unsigned u = ord ^ ((ord >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+                const double T = (double)__uint_as_float(u);
+                const float d1 = __uint_as_float((unsigned)(k1 >> 32));
+                const double d1n = (double)nextafterf(d1, INFINITY);
+                return T + qn - E > (a.squared ? (double)d1 : d1n * d1n);
+            };
+            // A stretch that gave a list both its entries: its other rows rank behind the second
+            // of them, which settles them unless that one is (nearly) the second nearest of
+            // all -- then every row of the stretch that the list's lanes saw is scored, two per
+            // lane, in the element order of the sums above.  (Earlier verdicts stay good: the
+            // second-best distance only falls.)
+            unsigned long long pending =
+                __builtin_amdgcn_ballot_w64(same_stretch >= 0 && !out_of_reach(second_key));
+            while (pending) {   // wave-uniform
+                const int holder = __builtin_ctzll(pending);
+                pending &= pending - 1;
+                const int first = __builtin_amdgcn_readlane(same_stretch, holder);
+                const int half = holder & 1, split = holder >> 1;
+                const int end = min(nt_rows, (split + 1) * split_rows);
+                __builtin_amdgcn_wave_barrier();
+                {   // the query row, for every lane to read
+                    const rowslice qv = *reinterpret_cast<const rowslice*>(qrow + KPL * lane);
+                    *reinterpret_cast<rowslice*>(terms + KPL * lane) = qv;
+                }
+                __builtin_amdgcn_wave_barrier();
+                int row[2];
+                float dist[2] = {0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = lane + 64 * h;   // tile of the stretch, place in the lane's column
+                    const int w = i & 31;
+                    row[h] = first + kTileRows * (i >> 5) + 32 * (w >> 4) + 8 * ((w >> 2) & 3) + 4 * half + (w & 3);
+                    if (i >= a.stretch_rows / 2 || row[h] >= end) row[h] = -1;
+                }
+                const floatx4* q4 = reinterpret_cast<const floatx4*>(terms);
+                const floatx4* t4a = reinterpret_cast<const floatx4*>(trows + (size_t)(row[0] < 0 ? 0 : row[0]) * K);
+                const floatx4* t4b = reinterpret_cast<const floatx4*>(trows + (size_t)(row[1] < 0 ? 0 : row[1]) * K);
+#pragma unroll 8
+                for (int j = 0; j < K / 4; ++j) {
+                    const floatx4 qq = q4[j];
+                    const floatx4 ua = qq - t4a[j], ub = qq - t4b[j];
+                    const floatx4 va = ua * ua, vb = ub * ub;
+                    dist[0] += va.x;
+                    dist[0] += va.y;
+                    dist[0] += va.z;
+                    dist[0] += va.w;
+                    dist[1] += vb.x;
+                    dist[1] += vb.y;
+                    dist[1] += vb.z;
+                    dist[1] += vb.w;
+                }
+                unsigned long long e[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float d = a.squared ? dist[h] : sqrtf(dist[h]);
+                    e[h] = row[h] < 0 ? ~0ull : ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)row[h];
+                }
+                const unsigned long long mine_lo = e[0] < e[1] ? e[0] : e[1], mine_hi = e[0] < e[1] ? e[1] : e[0];
+                const unsigned long long e0 = wave_min_u64(mine_lo);
+                const unsigned long long e1 = wave_min_u64(mine_lo == e0 ? mine_hi : mine_lo);
+                // best two of {k0, k1, e0, e1}; a row met twice carries the same key twice
+                const unsigned long long b0 = e0 < k0 ? e0 : k0;
+                unsigned long long b1 = ~0ull;
+                if (k0 != b0 && k0 < b1) b1 = k0;
+                if (k1 != b0 && k1 < b1) b1 = k1;
+                if (e0 != b0 && e0 < b1) b1 = e0;
+                if (e1 != b0 && e1 < b1) b1 = e1;
+                k0 = b0;
+                k1 = b1;
+            }
+            proven = others == 0xFFFFFFFFu || out_of_reach(others);
         }
     }
     if (a.force_exhaustive) proven = false;
@@ -1831,6 +1944,7 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int sq
     r.cand = s.cand;
     r.cand_key = s.cand_key;
     r.cand_third = s.cand_third;
+    r.stretch_rows = mode == kL2F32 ? 0 : kMergeTiles * kTileRows;
     r.q_norms = q.norms;
     r.t_norm_max = scratch_group_max(s) + t_group0;   // indexed by the train frame
     r.q_res = mode == kL2F16 ? q.res : nullptr;
