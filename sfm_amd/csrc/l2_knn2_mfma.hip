@@ -31,9 +31,14 @@
 //      difference between a row's sequential distance and its MFMA key + ||q||^2, the
 //      result is proven exact when T + ||q||^2 - E exceeds the re-scored second-best
 //      squared distance; a query for which it does not is appended to a list.
+//      (The narrow passes keep the best two of every stretch of 256 train rows, and the
+//      third key is the third-smallest among those: it bounds every row but the ones of a
+//      stretch that gave a list both its entries, which rank behind the second of them.  When
+//      that second is too near for the proof, the stretch is listed for pass 3.)
 //   3. Exhaustive pass over the listed queries (normally none): one workgroup per query
 //      recomputes the sequential distance to EVERY train row and takes the best two by
-//      (distance, train index).  Results are therefore always those of the sequential
+//      (distance, train index) -- and, for a listed stretch, to the rows of the stretch, joined
+//      to the result of pass 2.  Results are therefore always those of the sequential
 //      sum with the lower-index tie-break, whatever the rounding of the MFMA form.
 #include <algorithm>
 #include <cfloat>
@@ -99,7 +104,7 @@ struct L2Args {
     int qtiles, splits, blocks_per_group;
     int32_t* cand;  // [problem][split][rows_cap][4]
     float* cand_key;  // the candidates' ranking keys ||t||^2 - 2 q.t, same layout
-    float* cand_third;  // [problem][split][rows_cap][2]: third-smallest key of each candidate list
+    float* cand_third;  // [problem][split][rows_cap][2]: third-smallest key of each candidate list (narrow passes: among the best two of every stretch, see RescoreArgs::stretch_rows)
     // fp16 pass: the last fold_groups workgroups of the launch do not rank; they fold what
     // l2_pack_kernel and l2_narrow_kernel left per workgroup into the groups' largest norms and
     // residual norms, which the re-score pass reads (a launch of their own would cost more
@@ -421,8 +426,8 @@ __device__ __forceinline__ floatx16 narrow_mfma(halfx8 a, halfx8 b, floatx16 c) 
 // sequential one.  Layout and staging are those of the fp32 kernel: a split row is 2 K bfloat16
 // = K floats wide, upper halves first.  A wave owns one 32-query column block (NT = 1) and two
 // waves share a SIMD: one wave issues a vector instruction every six cycles at best, two
-// interleave, and the fold -- four instructions per key -- runs underneath the matrix
-// instructions of the next tile.
+// interleave, and the fold -- a tag and five instructions per four keys -- runs underneath the
+// matrix instructions of the next tile.
 //
 // F16 (the default): the narrow rows are single fp16 copies x * s of the floats, s a power of
 // two common to all rows that brings the largest below 2^15 (l2_narrow_kernel), and q.t is one
@@ -587,12 +592,14 @@ void l2_candidates_narrow_kernel(L2Args a) {
     // the kNarrowTagBits low mantissa bits of one are replaced by a tag (a change below
     // 2^(kNarrowTagBits - 23) of its size, which the error bound of the re-score pass covers):
     // its position in the tile in the five low bits (an inline constant of the instruction),
-    // zero above.  The three largest of a stretch of kMergeTiles tiles fall out of one maximum
-    // and two medians each with no train index carried along: before the next tile of the
-    // stretch is folded, 32 is added to the bit patterns of the three (age_tops: the upper tag
-    // bits count the tiles folded since, the order of the three stays), so the tagged values
-    // of a stretch are all different.  Only the largest two then enter the running lists, once
-    // per stretch, as keys, with the train row their tags name.
+    // zero above.  The two largest of a stretch of kMergeTiles tiles fall out of medians and
+    // maxima of three with no train index carried along (fold_pair): before the next tile of the
+    // stretch is folded, 32 is added to the bit patterns of the two (age_tops: the upper tag
+    // bits count the tiles folded since, their order stays), so the tagged values of a stretch
+    // are all different.  The two enter the running lists once per stretch, as keys, with the
+    // train row their tags name.  (Keeping the third largest as well, which makes cand_third
+    // a bound on every row outside the lists, costs three instructions per key instead of
+    // five per four: 121 against 107 us on 20 000 x 20 000 x 128.)
     constexpr unsigned kTagMask = (1u << kNarrowTagBits) - 1u;
     float top0[NT], top1[NT];
     auto tagged = [&](const floatx16 (&acc)[2][NT], int kq) {
@@ -635,8 +642,8 @@ void l2_candidates_narrow_kernel(L2Args a) {
     };
     // which = 0, 1: the largest, second-largest accumulator of the stretch whose last folded
     // tile starts at train row tbase enters the lists of column n as a key (strict
-    // comparisons: of equal keys the earlier stretch stays ahead); which = 2: the third only
-    // moves the third-smallest key seen.
+    // comparisons: of equal keys the earlier stretch stays ahead), and moves the third-smallest
+    // key seen.
     auto merge = [&](int n, int which, int tbase) {
         const float v = which == 0 ? top0[n] : top1[n];
         const float key = -2.f * v;   // exact
@@ -846,7 +853,7 @@ struct PackArgs {
     PackSet set[2];
     int blocks0;   // workgroups of set 0; the rest serve set 1
     int dim, K;
-    int32_t* clear[3];   // counters of later kernels that this launch zeroes (or null)
+    int32_t* clear[4];   // counters of later kernels that this launch zeroes (or null)
 };
 // ALIGNED: every row starts on an 8-byte boundary and dim is even; SPLIT: the bfloat16 halves are written.
 template <bool ALIGNED, bool SPLIT>
@@ -861,7 +868,7 @@ __global__ __launch_bounds__(kPackBlock) void l2_pack_kernel(PackArgs a) {
     int group[kPackRowsPerWave], local[kPackRowsPerWave];
     walk_rows(row0, p.rows, p.rows_per_group, group, local);
     const int K = a.K;
-    if (blockIdx.x == 0 && threadIdx.x < 3 && a.clear[threadIdx.x]) *a.clear[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 4 && a.clear[threadIdx.x]) *a.clear[threadIdx.x] = 0;
     // A lane takes element pairs lane and lane + 64 of a row (K <= 256: at most 128 pairs; the
     // second pair only exists for K = 256).  All the loads of the wave's rows go out before the
     // first value is used: a lane past the row's end reads the row's last elements instead and
@@ -1146,10 +1153,19 @@ struct RescoreArgs {
     const float* q_res;      // fp16 pass: residual norm of every query row (rows_cap per frame), or null
     const float* t_res_max;  // fp16 pass, per train frame: the largest residual norm of its rows in use
     int force_exhaustive;
+    int count_stretches;   // the statistics count the stretch entries too (a measuring aid)
     int32_t* knn_idx;  // [problem][rows_cap][2]
     float* knn_dist;
     int32_t* todo_count;  // queries whose result is not proven: count, then (problem, query) pairs
     int32_t* todo;
+    // Queries proven but for one stretch of one list (see stretch_rows): count, and entries of
+    // eight numbers -- problem, query, first row and end of the stretch, query frame, train
+    // frame -- which say all that l2_exhaustive_kernel needs to start loading (a chain of
+    // look-ups per entry would cost it more than the sums).  When the array is full the query
+    // goes to the exhaustive pass proper.
+    int32_t* stretch_count;
+    int32_t* stretch_items;
+    int stretch_cap;
     int32_t* exhaustive_done;  // workgroups of the exhaustive pass that have finished (zero between launches)
     int32_t* stat_exhaustive;  // per-context total of such queries since the entry point began
     unsigned long long* partial;  // exhaustive pass: best two of every (entry, slice)
@@ -1196,6 +1212,7 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {   // same moves a
 }
 
 constexpr int kRescored = 8;  // candidates per query whose distance is recomputed
+constexpr int kStretchCap = 1 << 16;    // entries of RescoreArgs::stretch_items
 
 // One wave per (problem, query): lane c holds candidate c of the query (four per train
 // split).  The kRescored candidates with the smallest ranking keys are re-scored; the rest
@@ -1335,8 +1352,8 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
         if (!a.squared) d = sqrtf(d);  // batchDistL2_32f
         key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)mine;
     }
-    unsigned long long k0 = wave_min_u64(key);
-    unsigned long long k1 = wave_min_u64(key == k0 ? ~0ull : key);
+    const unsigned long long k0 = wave_min_u64(key);
+    const unsigned long long k1 = wave_min_u64(key == k0 ? ~0ull : key);
     // Proof that no other row can reach the second place: its sequential squared distance is
     // at least its ranking key + ||q||^2 - E >= T + ||q||^2 - E.  E bounds the rounding of the
     // norms (pairwise sums), of the K accumulation steps of the matrix pipe (each at most one
@@ -1372,69 +1389,31 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
             };
             // A stretch that gave a list both its entries: its other rows rank behind the second
             // of them, which settles them unless that one is (nearly) the second nearest of
-            // all -- then every row of the stretch that the list's lanes saw is scored, two per
-            // lane, in the element order of the sums above.  (Earlier verdicts stay good: the
-            // second-best distance only falls.)
-            unsigned long long pending =
+            // all.  Then the stretch is left to l2_exhaustive_kernel, which scores its rows one
+            // by one and joins them to the result written below -- every other row is out of
+            // reach of the second place as it stands, and the second-best distance only falls.
+            // Two such stretches (rare) send the query to the exhaustive pass proper.
+            const unsigned long long pending =
                 __builtin_amdgcn_ballot_w64(same_stretch >= 0 && !out_of_reach(second_key));
-            while (pending) {   // wave-uniform
-                const int holder = __builtin_ctzll(pending);
-                pending &= pending - 1;
-                const int first = __builtin_amdgcn_readlane(same_stretch, holder);
-                const int half = holder & 1, split = holder >> 1;
-                const int end = min(nt_rows, (split + 1) * split_rows);
-                __builtin_amdgcn_wave_barrier();
-                {   // the query row, for every lane to read
-                    const rowslice qv = *reinterpret_cast<const rowslice*>(qrow + KPL * lane);
-                    *reinterpret_cast<rowslice*>(terms + KPL * lane) = qv;
-                }
-                __builtin_amdgcn_wave_barrier();
-                int row[2];
-                float dist[2] = {0.f, 0.f};
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int i = lane + 64 * h;   // tile of the stretch, place in the lane's column
-                    const int w = i & 31;
-                    row[h] = first + kTileRows * (i >> 5) + 32 * (w >> 4) + 8 * ((w >> 2) & 3) + 4 * half + (w & 3);
-                    if (i >= a.stretch_rows / 2 || row[h] >= end) row[h] = -1;
-                }
-                const floatx4* q4 = reinterpret_cast<const floatx4*>(terms);
-                const floatx4* t4a = reinterpret_cast<const floatx4*>(trows + (size_t)(row[0] < 0 ? 0 : row[0]) * K);
-                const floatx4* t4b = reinterpret_cast<const floatx4*>(trows + (size_t)(row[1] < 0 ? 0 : row[1]) * K);
-#pragma unroll 8
-                for (int j = 0; j < K / 4; ++j) {
-                    const floatx4 qq = q4[j];
-                    const floatx4 ua = qq - t4a[j], ub = qq - t4b[j];
-                    const floatx4 va = ua * ua, vb = ub * ub;
-                    dist[0] += va.x;
-                    dist[0] += va.y;
-                    dist[0] += va.z;
-                    dist[0] += va.w;
-                    dist[1] += vb.x;
-                    dist[1] += vb.y;
-                    dist[1] += vb.z;
-                    dist[1] += vb.w;
-                }
-                unsigned long long e[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float d = a.squared ? dist[h] : sqrtf(dist[h]);
-                    e[h] = row[h] < 0 ? ~0ull : ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)row[h];
-                }
-                const unsigned long long mine_lo = e[0] < e[1] ? e[0] : e[1], mine_hi = e[0] < e[1] ? e[1] : e[0];
-                const unsigned long long e0 = wave_min_u64(mine_lo);
-                const unsigned long long e1 = wave_min_u64(mine_lo == e0 ? mine_hi : mine_lo);
-                // best two of {k0, k1, e0, e1}; a row met twice carries the same key twice
-                const unsigned long long b0 = e0 < k0 ? e0 : k0;
-                unsigned long long b1 = ~0ull;
-                if (k0 != b0 && k0 < b1) b1 = k0;
-                if (k1 != b0 && k1 < b1) b1 = k1;
-                if (e0 != b0 && e0 < b1) b1 = e0;
-                if (e1 != b0 && e1 < b1) b1 = e1;
-                k0 = b0;
-                k1 = b1;
-            }
             proven = others == 0xFFFFFFFFu || out_of_reach(others);
+            if (proven && pending) {
+                const int holder = __builtin_ctzll(pending);
+                const int first = __builtin_amdgcn_readlane(same_stretch, holder);
+                int slot = 0;
+                if (!(pending & (pending - 1)) && !a.force_exhaustive) {
+                    if (lane == 0) slot = atomicAdd(a.stretch_count, 1);
+                    slot = __builtin_amdgcn_readfirstlane(slot);
+                }
+                if ((pending & (pending - 1)) || slot >= a.stretch_cap) {
+                    proven = false;   // (a count above the capacity is read as the capacity)
+                } else if (lane == 0 && !a.force_exhaustive) {
+                    typedef int intx4 __attribute__((ext_vector_type(4)));
+                    intx4* item = reinterpret_cast<intx4*>(a.stretch_items + 8 * (size_t)slot);
+                    item[0] = intx4{problem, q, first, min(nt_rows, ((holder >> 1) + 1) * split_rows)};
+                    item[1] = intx4{qf, tf, 0, 0};
+                    if (a.count_stretches) atomicAdd(a.stat_exhaustive, 1);
+                }
+            }
         }
     }
     if (a.force_exhaustive) proven = false;
@@ -1477,11 +1456,106 @@ __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
     constexpr int K = 64 * KPL;
     __shared__ __attribute__((aligned(16))) float s_q[kExQueries][K];
     __shared__ unsigned long long s_red[kBlock / 64][kExQueries][2];
+    typedef int intx4 __attribute__((ext_vector_type(4)));
+    // (a workgroup's first entry is read beside the counts, not behind them: whatever the
+    // array holds there, it is only used below the count)
+    const intx4* first_entry = reinterpret_cast<const intx4*>(a.stretch_items + 8 * (size_t)(blockIdx.x % a.stretch_cap));
+    intx4 e0 = first_entry[0], e1 = first_entry[1];
     const int count = *a.todo_count;
+    const int stretches = min(*a.stretch_count, a.stretch_cap);
+    if (count == 0 && stretches == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Stretches of single lists (see RescoreArgs): a workgroup per entry, a thread per row of
+    // the stretch -- the rows of both lane halves, the list's own are among them --, distances in
+    // the element order of the re-score pass, joined to the two that pass wrote.
+    for (int item = blockIdx.x; item < stretches; item += gridDim.x) {
+        if (item != (int)blockIdx.x) {
+            e0 = reinterpret_cast<const intx4*>(a.stretch_items + 8 * (size_t)item)[0];
+            e1 = reinterpret_cast<const intx4*>(a.stretch_items + 8 * (size_t)item)[1];
+        }
+        const int problem = e0.x, q = e0.y, first = e0.z, end = e0.w, qf = e1.x, tf = e1.y;
+        const float* trows = a.t_base + (size_t)tf * a.frame_floats;
+        const float* qrow = a.q_base + (size_t)qf * a.frame_floats + (size_t)q * K;
+        // the result so far (thread 0 joins the stretch to it at the end)
+        const size_t o = ((size_t)problem * a.rows_cap + q) * 2;
+        int was_idx[2] = {-1, -1};
+        float was_dist[2] = {0.f, 0.f};
+        if (tid == 0) {
+            was_idx[0] = a.knn_idx[o];
+            was_idx[1] = a.knn_idx[o + 1];
+            was_dist[0] = a.knn_dist[o];
+            was_dist[1] = a.knn_dist[o + 1];
+        }
+        __syncthreads();   // s_q, s_red of the entry before are done with
+        for (int i = tid; i < K / 4; i += kBlock)
+            *reinterpret_cast<floatx4*>(&s_q[0][4 * i]) = *reinterpret_cast<const floatx4*>(qrow + 4 * i);
+        __syncthreads();
+        unsigned long long key = ~0ull;
+        for (int r0 = 0; r0 < a.stretch_rows; r0 += kBlock) {   // (one round: a stretch is kBlock rows)
+            const int row = first + r0 + tid;
+            if (r0 + tid < a.stretch_rows && row < end) {
+                const floatx4* t4 = reinterpret_cast<const floatx4*>(trows + (size_t)row * K);
+                float d = 0.f;
+                // (every load of up to 32 chunks goes out before the first sum: a thread's row
+                // is its own, and what this costs is the latency of its loads)
+                constexpr int kBatch = K / 4 < 32 ? K / 4 : 32;
+#pragma unroll 1
+                for (int j0 = 0; j0 < K / 4; j0 += kBatch) {
+                    floatx4 tv[kBatch];
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) tv[j] = t4[j0 + j];
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) {
+                        const floatx4 qq = *reinterpret_cast<const floatx4*>(&s_q[0][4 * (j0 + j)]);
+                        const floatx4 u = qq - tv[j];
+                        const floatx4 v = u * u;
+                        d += v.x;
+                        d += v.y;
+                        d += v.z;
+                        d += v.w;
+                    }
+                }
+                if (!a.squared) d = sqrtf(d);
+                const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)row;
+                key = k < key ? k : key;   // (one round, see above; more would need the best two here)
+            }
+        }
+        const unsigned long long w0 = wave_min_u64(key);
+        const unsigned long long w1 = wave_min_u64(key == w0 ? ~0ull : key);
+        if (lane == 0) {
+            s_red[wave][0][0] = w0;
+            s_red[wave][0][1] = w1;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // best two of the re-score pass's result and the stretch; a row met twice carries
+            // the same key twice
+            unsigned long long k0 = ~0ull, k1 = ~0ull;
+            auto take = [&](unsigned long long k) {
+                if (k == k0 || k == k1) return;
+                if (k < k0) {
+                    k1 = k0;
+                    k0 = k;
+                } else if (k < k1) {
+                    k1 = k;
+                }
+            };
+            for (int r = 0; r < 2; ++r)
+                if (was_idx[r] >= 0)
+                    take(((unsigned long long)__float_as_uint(was_dist[r]) << 32) | (unsigned)was_idx[r]);
+            for (int w = 0; w < kBlock / 64; ++w) {
+                take(s_red[w][0][0]);
+                take(s_red[w][0][1]);
+            }
+            a.knn_idx[o] = k0 == ~0ull ? -1 : (int32_t)(k0 & 0xFFFFFFFFu);
+            a.knn_idx[o + 1] = k1 == ~0ull ? -1 : (int32_t)(k1 & 0xFFFFFFFFu);
+            a.knn_dist[o] = k0 == ~0ull ? FLT_MAX : __uint_as_float((unsigned)(k0 >> 32));
+            a.knn_dist[o + 1] = k1 == ~0ull ? FLT_MAX : __uint_as_float((unsigned)(k1 >> 32));
+        }
+    }
     if (count == 0) return;
     const int groups = (count + kExQueries - 1) / kExQueries;
     const int slices = exhaustive_slices(groups, gridDim.x);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int item = blockIdx.x; item < groups * slices; item += gridDim.x) {
         const int e0 = (item / slices) * kExQueries, slice = item % slices;
         const int ne = min(kExQueries, count - e0);
@@ -1716,6 +1790,7 @@ struct L2Scratch {
     float* scalars;      // see below
     int groups;          // groups of rows (frames; queries and train rows) with maxima of their own
     int32_t* todo;       // [problems][rows_cap][2]
+    int32_t* stretch_items;   // [kStretchCap][8]
     unsigned long long* partial;  // [max(problems x rows_cap, kExQueries x kExhaustiveGrid)][2]
     int32_t* knn_idx;    // [problems][rows_cap][2]
     float* knn_dist;
@@ -1724,7 +1799,7 @@ constexpr int kExhaustiveGrid = 1024;
 // scalars: [count of listed queries][finished workgroups of the exhaustive pass][largest norm
 // of all rows][largest norm per group ...][largest residual per group ...][s^2][1 / s^2].  The
 // two counters are cleared by l2_pack_kernel.
-enum { kScalarTodoCount = 0, kScalarExhaustiveDone, kScalarGlobalMax, kScalarGroups };
+enum { kScalarTodoCount = 0, kScalarStretchCount, kScalarExhaustiveDone, kScalarGlobalMax, kScalarGroups };
 inline float* scratch_group_max(const L2Scratch& s) { return s.scalars + kScalarGroups; }
 inline float* scratch_group_res(const L2Scratch& s) { return s.scalars + kScalarGroups + s.groups; }
 inline float* scratch_scale(const L2Scratch& s) { return s.scalars + kScalarGroups + 2 * s.groups; }
@@ -1735,6 +1810,7 @@ void l2_scratch_carve(Carver& c, const L2Plan& plan, int rows_cap, size_t n_prob
     s->groups = groups;
     s->scalars = c.take<float>(kScalarGroups + 2 * (size_t)groups + 2);
     s->todo = c.take<int32_t>(n_problems * rows_cap * 2);
+    s->stretch_items = c.take<int32_t>((size_t)kStretchCap * 8);
     s->partial = c.take<unsigned long long>(
         std::max<size_t>(n_problems * rows_cap, (size_t)kExQueries * kExhaustiveGrid) * 2);
     s->knn_idx = c.take<int32_t>(n_problems * rows_cap * 2);
@@ -1836,6 +1912,7 @@ int l2_pack(sfm_ctx* ctx, L2Mode mode, const L2Source& src0, L2Rows* rows0, cons
     a.clear[0] = counters + kScalarTodoCount;
     a.clear[1] = counters + kScalarExhaustiveDone;
     a.clear[2] = ctx->stats;
+    a.clear[3] = counters + kScalarStretchCount;
     a.dim = dim;
     a.K = n.K = K;
     bool aligned = dim % 2 == 0;   // rows of an even number of floats on 8-byte boundaries
@@ -1920,7 +1997,8 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int sq
         grid += a.fold_groups;
     }
     if (grid > 0x7fffffffL) return set_error(ctx, SFM_E_INVALID, "knn launch too large");
-    if (clear_todo) SFM_HIP_CHECK(ctx, hipMemsetAsync(todo_count, 0, sizeof(int32_t), ctx->stream));
+    static_assert(kScalarStretchCount == kScalarTodoCount + 1, "the two counts are cleared together");
+    if (clear_todo) SFM_HIP_CHECK(ctx, hipMemsetAsync(todo_count, 0, 2 * sizeof(int32_t), ctx->stream));
     if (plan.K == 64)
         SFM_RETURN_IF((launch_candidates<64, 2>(ctx, a, grid, mode)));
     else if (plan.K == 128)
@@ -1962,10 +2040,17 @@ int l2_knn_packed(sfm_ctx* ctx, const L2Plan& plan, L2Mode mode, int dim, int sq
                   : mode == kL2F16 ? (4.0 * plan.K + 64.0) * eps + tag + narrow_tag
                                    : (12.0 * plan.K + 64.0) * eps + 5.0 * tag + narrow_tag;
     r.force_exhaustive = l2_force_exhaustive() ? 1 : 0;
+    {   // SFM_L2_COUNT_STRETCHES=1: sfm_l2_exhaustive_count counts the stretch entries too
+        const char* e = getenv("SFM_L2_COUNT_STRETCHES");
+        r.count_stretches = e && e[0] == '1' ? 1 : 0;
+    }
     r.knn_idx = s.knn_idx;
     r.knn_dist = s.knn_dist;
     r.todo_count = todo_count;
     r.todo = s.todo;
+    r.stretch_count = reinterpret_cast<int32_t*>(s.scalars + kScalarStretchCount);
+    r.stretch_items = s.stretch_items;
+    r.stretch_cap = kStretchCap;
     r.exhaustive_done = reinterpret_cast<int32_t*>(s.scalars + kScalarExhaustiveDone);
     r.stat_exhaustive = ctx->stats;
     r.partial = s.partial;
