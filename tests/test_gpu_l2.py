@@ -126,6 +126,13 @@ def test_l2_neighbours_planted_across_tiles(ctx, oracle, monkeypatch, nt, mode):
     np.testing.assert_array_equal(idx, oidx)
     np.testing.assert_array_equal(dist, odist)
     assert ctx.l2_exhaustive_count() <= 3
+    # the queries whose two nearest rows sit in one stretch of one lane's rows had that stretch
+    # scored row by row (SFM_L2_COUNT_STRETCHES=1 counts them with the exhaustive ones)
+    monkeypatch.setenv("SFM_L2_COUNT_STRETCHES", "1")
+    idx, dist = ctx.knn2(capi.NORM_L2SQR, q, t)
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_array_equal(dist, odist)
+    assert 10 <= ctx.l2_exhaustive_count() <= nq
 
 
 @pytest.mark.parametrize("norm_name,ratio", [("L2", 0.7), ("L2SQR", 0.5)])
