@@ -1160,7 +1160,7 @@ struct RescoreArgs {
     int32_t* todo;
     // Queries proven but for one stretch of one list (see stretch_rows): count, and entries of
     // eight numbers -- problem, query, first row and end of the stretch, query frame, train
-    // frame -- which say all that l2_exhaustive_kernel needs to start loading (a chain of
+    // frame, lane half of the list -- which say all that l2_exhaustive_kernel needs to start loading (a chain of
     // look-ups per entry would cost it more than the sums).  When the array is full the query
     // goes to the exhaustive pass proper.
     int32_t* stretch_count;
@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
                     typedef int intx4 __attribute__((ext_vector_type(4)));
                     intx4* item = reinterpret_cast<intx4*>(a.stretch_items + 8 * (size_t)slot);
                     item[0] = intx4{problem, q, first, min(nt_rows, ((holder >> 1) + 1) * split_rows)};
-                    item[1] = intx4{qf, tf, 0, 0};
+                    item[1] = intx4{qf, tf, holder & 1, 0};
                     if (a.count_stretches) atomicAdd(a.stat_exhaustive, 1);
                 }
             }
@@ -1465,15 +1465,15 @@ __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
     const int stretches = min(*a.stretch_count, a.stretch_cap);
     if (count == 0 && stretches == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Stretches of single lists (see RescoreArgs): a workgroup per entry, a thread per row of
-    // the stretch -- the rows of both lane halves, the list's own are among them --, distances in
+    // Stretches of single lists (see RescoreArgs): a workgroup per entry, a thread per row that
+    // the list's lanes saw of the stretch, distances in
     // the element order of the re-score pass, joined to the two that pass wrote.
     for (int item = blockIdx.x; item < stretches; item += gridDim.x) {
         if (item != (int)blockIdx.x) {
             e0 = reinterpret_cast<const intx4*>(a.stretch_items + 8 * (size_t)item)[0];
             e1 = reinterpret_cast<const intx4*>(a.stretch_items + 8 * (size_t)item)[1];
         }
-        const int problem = e0.x, q = e0.y, first = e0.z, end = e0.w, qf = e1.x, tf = e1.y;
+        const int problem = e0.x, q = e0.y, first = e0.z, end = e0.w, qf = e1.x, tf = e1.y, half = e1.z;
         const float* trows = a.t_base + (size_t)tf * a.frame_floats;
         const float* qrow = a.q_base + (size_t)qf * a.frame_floats + (size_t)q * K;
         // the result so far (thread 0 joins the stretch to it at the end)
@@ -1491,9 +1491,12 @@ __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
             *reinterpret_cast<floatx4*>(&s_q[0][4 * i]) = *reinterpret_cast<const floatx4*>(qrow + 4 * i);
         __syncthreads();
         unsigned long long key = ~0ull;
-        for (int r0 = 0; r0 < a.stretch_rows; r0 += kBlock) {   // (one round: a stretch is kBlock rows)
-            const int row = first + r0 + tid;
-            if (r0 + tid < a.stretch_rows && row < end) {
+        // the rows the list's lanes saw: every other group of four (half the memory instructions
+        // of the whole stretch, and it is their number that this costs)
+        for (int r0 = 0; r0 < a.stretch_rows / 2; r0 += kBlock) {   // (one round: half a stretch is below kBlock rows)
+            const int i = r0 + tid;
+            const int row = first + 8 * (i >> 2) + 4 * half + (i & 3);
+            if (i < a.stretch_rows / 2 && row < end) {
                 const floatx4* t4 = reinterpret_cast<const floatx4*>(trows + (size_t)row * K);
                 float d = 0.f;
                 // (every load of up to 32 chunks goes out before the first sum: a thread's row
