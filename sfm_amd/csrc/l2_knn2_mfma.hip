@@ -1300,8 +1300,8 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
         const unsigned key1 = __shfl(held_key, (2 * lane + 1) & 63);
         const int first = (lane >> 1) * split_rows;
         if (lane < 2 * a.splits && i0 >= 0 && i1 >= 0 &&
-            (i0 - first) / a.stretch_rows == (i1 - first) / a.stretch_rows) {
-            same_stretch = first + (i0 - first) / a.stretch_rows * a.stretch_rows;
+            ((i0 - first) ^ (i1 - first)) < a.stretch_rows) {   // (a power of two; both at or above first)
+            same_stretch = first + ((i0 - first) & ~(a.stretch_rows - 1));
             second_key = key1;
         }
     }
