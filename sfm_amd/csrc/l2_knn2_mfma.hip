@@ -1439,8 +1439,11 @@ constexpr int kExRows = 4;       // train rows a thread works on at a time
 
 // Slices of the train rows per group: a short list is spread over the whole launch (one
 // workgroup alone takes 0.4 ms for 20 000 rows of 128), a long one gets a workgroup per group.
-__device__ __forceinline__ int exhaustive_slices(int groups, int grid) {
-    return groups >= grid ? 1 : min(64, grid / groups);
+// With few groups the slices shrink to a row per thread (rows_cap bounds every train set), which
+// spares the loads and sums of the three other rows a thread would otherwise carry: four listed
+// queries of 20 000 x 20 000 x 128 cost 117 us with 64 slices of 313 rows.
+__device__ __forceinline__ int exhaustive_slices(int groups, int grid, int rows_cap) {
+    return groups >= grid ? 1 : min(max(64, (rows_cap + kBlock - 1) / kBlock), grid / groups);
 }
 
 // The listed queries against every train row: one workgroup per (group of entries, slice of the
@@ -1558,7 +1561,7 @@ __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
     }
     if (count == 0) return;
     const int groups = (count + kExQueries - 1) / kExQueries;
-    const int slices = exhaustive_slices(groups, gridDim.x);
+    const int slices = exhaustive_slices(groups, gridDim.x, a.rows_cap);
     for (int item = blockIdx.x; item < groups * slices; item += gridDim.x) {
         const int e0 = (item / slices) * kExQueries, slice = item % slices;
         const int ne = min(kExQueries, count - e0);
@@ -1598,37 +1601,45 @@ __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
                 bd0[qq] = bd1[qq] = INFINITY;
                 bi0[qq] = bi1[qq] = -1;
             }
-            for (int t0 = t_begin + tid; t0 < t_end; t0 += kExRows * kBlock) {
-                float d[kExRows][kExQueries];
+            auto scan = [&](auto rows_per_thread) {
+            constexpr int R = decltype(rows_per_thread)::value;
+            for (int t0 = t_begin + tid; t0 < t_end; t0 += R * kBlock) {
+                float d[R][kExQueries];
 #pragma unroll
-                for (int r = 0; r < kExRows; ++r)
+                for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int qq = 0; qq < kExQueries; ++qq) d[r][qq] = 0.f;
-                const floatx4* trow[kExRows];
+                const floatx4* trow[R];
 #pragma unroll
-                for (int r = 0; r < kExRows; ++r)   // a row past the slice re-reads the last one
+                for (int r = 0; r < R; ++r)   // a row past the slice re-reads the last one
                     trow[r] = reinterpret_cast<const floatx4*>(trows + (size_t)min(t0 + r * kBlock, t_end - 1) * K);
-#pragma unroll 2
-                for (int j4 = 0; j4 < K / 4; ++j4) {
-                    floatx4 tv[kExRows];
+                constexpr int kAhead = R == 1 ? 8 : 2;   // chunks of a row whose loads go out together
+                static_assert((K / 4) % kAhead == 0, "whole batches");
+#pragma unroll 1
+                for (int j0 = 0; j0 < K / 4; j0 += kAhead) {
+                    floatx4 tv[kAhead][R];
 #pragma unroll
-                    for (int r = 0; r < kExRows; ++r) tv[r] = trow[r][j4];
+                    for (int u = 0; u < kAhead; ++u)
 #pragma unroll
-                    for (int qq = 0; qq < kExQueries; ++qq) {
-                        const floatx4 qv = *reinterpret_cast<const floatx4*>(&s_q[qq][4 * j4]);
+                        for (int r = 0; r < R; ++r) tv[u][r] = trow[r][j0 + u];
 #pragma unroll
-                        for (int r = 0; r < kExRows; ++r) {
-                            const float v0 = qv.x - tv[r].x, v1 = qv.y - tv[r].y, v2 = qv.z - tv[r].z,
-                                        v3 = qv.w - tv[r].w;
-                            d[r][qq] += v0 * v0;
-                            d[r][qq] += v1 * v1;
-                            d[r][qq] += v2 * v2;
-                            d[r][qq] += v3 * v3;
+                    for (int u = 0; u < kAhead; ++u)
+#pragma unroll
+                        for (int qq = 0; qq < kExQueries; ++qq) {
+                            const floatx4 qv = *reinterpret_cast<const floatx4*>(&s_q[qq][4 * (j0 + u)]);
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                const float v0 = qv.x - tv[u][r].x, v1 = qv.y - tv[u][r].y, v2 = qv.z - tv[u][r].z,
+                                            v3 = qv.w - tv[u][r].w;
+                                d[r][qq] += v0 * v0;
+                                d[r][qq] += v1 * v1;
+                                d[r][qq] += v2 * v2;
+                                d[r][qq] += v3 * v3;
+                            }
                         }
-                    }
                 }
 #pragma unroll
-                for (int r = 0; r < kExRows; ++r) {
+                for (int r = 0; r < R; ++r) {
                     const int t = t0 + r * kBlock;
                     if (t < t_end) {
 #pragma unroll
@@ -1647,6 +1658,11 @@ __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
                     }
                 }
             }
+            };
+            if (t_end - t_begin <= kBlock)   // (wave-uniform)
+                scan(std::integral_constant<int, 1>());
+            else
+                scan(std::integral_constant<int, kExRows>());
             // best two of the workgroup per query: the smallest key, then the smallest of what is
             // left (keys are distinct: they hold the index)
 #pragma unroll
@@ -1684,14 +1700,49 @@ __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
     }
     // The slices are joined by whichever workgroup finishes last: every workgroup publishes its
     // stores and counts itself; the one that counts to the size of the launch sees them all.
+    // (Only the workgroups that had an item count, and one thread of each publishes: a release
+    // by every thread of a launch of 1024 workgroups cost 100 us for four listed queries.)
+    const int working = min((int)gridDim.x, groups * slices);
+    if ((int)blockIdx.x >= working) return;
     __shared__ int s_last;
-    __threadfence();
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(a.exhaustive_done, 1) == (int)gridDim.x - 1;
+    if (tid == 0) {
+        __threadfence();
+        s_last = atomicAdd(a.exhaustive_done, 1) == working - 1;
+    }
     __syncthreads();
     if (!s_last) return;
     __threadfence();
     if (tid == 0) *a.exhaustive_done = 0;   // for the next launch
+    auto write_entry = [&](int e, unsigned long long k0, unsigned long long k1) {
+        const int problem = a.todo[2 * (size_t)e], q = a.todo[2 * (size_t)e + 1];
+        const size_t o = ((size_t)problem * a.rows_cap + q) * 2;
+        const float d0 = __uint_as_float((unsigned)(k0 >> 32)), d1 = __uint_as_float((unsigned)(k1 >> 32));
+        a.knn_idx[o] = k0 == ~0ull ? -1 : (int32_t)(k0 & 0xFFFFFFFFu);
+        a.knn_idx[o + 1] = k1 == ~0ull ? -1 : (int32_t)(k1 & 0xFFFFFFFFu);
+        a.knn_dist[o] = k0 == ~0ull ? FLT_MAX : d0;
+        a.knn_dist[o + 1] = k1 == ~0ull ? FLT_MAX : d1;
+    };
+    if (slices > 4) {
+        // a short list in many slices: a wave per entry, a lane per few slices (one thread per
+        // entry would read its 2 x slices values one behind the other)
+        for (int e = wave; e < count; e += kBlock / 64) {
+            unsigned long long k0 = ~0ull, k1 = ~0ull;
+            for (int i = lane; i < 2 * slices; i += 64) {
+                const unsigned long long key = a.partial[2 * (size_t)e * slices + i];
+                if (key < k0) {
+                    k1 = k0;
+                    k0 = key;
+                } else if (key < k1) {
+                    k1 = key;
+                }
+            }
+            const unsigned long long w0 = wave_min_u64(k0);
+            const unsigned long long w1 = wave_min_u64(k0 == w0 ? k1 : k0);
+            if (lane == 0) write_entry(e, w0, w1);
+        }
+        return;
+    }
     for (int e = tid; e < count; e += kBlock) {
         unsigned long long k0 = ~0ull, k1 = ~0ull;
         for (int i = 0; i < 2 * slices; ++i) {
@@ -1703,13 +1754,7 @@ __global__ __launch_bounds__(kBlock) void l2_exhaustive_kernel(RescoreArgs a) {
                 k1 = key;
             }
         }
-        const int problem = a.todo[2 * (size_t)e], q = a.todo[2 * (size_t)e + 1];
-        const size_t o = ((size_t)problem * a.rows_cap + q) * 2;
-        const float d0 = __uint_as_float((unsigned)(k0 >> 32)), d1 = __uint_as_float((unsigned)(k1 >> 32));
-        a.knn_idx[o] = k0 == ~0ull ? -1 : (int32_t)(k0 & 0xFFFFFFFFu);
-        a.knn_idx[o + 1] = k1 == ~0ull ? -1 : (int32_t)(k1 & 0xFFFFFFFFu);
-        a.knn_dist[o] = k0 == ~0ull ? FLT_MAX : d0;
-        a.knn_dist[o + 1] = k1 == ~0ull ? FLT_MAX : d1;
+        write_entry(e, k0, k1);
     }
 }
 
