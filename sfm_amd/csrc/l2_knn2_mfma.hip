@@ -21,12 +21,13 @@
 //      selects a three-product bfloat16 split (bf16) or v_mfma_f32_32x32x2_f32 on the floats
 //      themselves (f32, l2_candidates_kernel).
 //      The key only ranks: its rounding is covered by the proof of pass 2.
-//   2. Re-score pass.  For the eight candidates of a query with the smallest ranking
-//      keys the squared distance is recomputed as the sequential float sum
+//   2. Re-score pass.  For the four candidates of a query with the smallest ranking
+//      keys -- and the next four when the fifth key could still reach the second place -- the
+//      squared distance is recomputed as the sequential float sum
 //      d += (a-b)*(a-b)  (the scalar order of OpenCV's normL2Sqr), the square root
 //      is taken for NORM_L2, and the best two are chosen by (distance, train index).
 //      Every train row that was NOT re-scored has a ranking key at least T = the smaller
-//      of the ninth-smallest candidate key and the third-smallest key of any candidate
+//      of the smallest candidate key not re-scored and the third-smallest key of any candidate
 //      list (the candidate pass keeps that third key too).  With a bound E on the
 //      difference between a row's sequential distance and its MFMA key + ||q||^2, the
 //      result is proven exact when T + ||q||^2 - E exceeds the re-scored second-best
@@ -1196,11 +1197,22 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Smallest v of lanes 0 .. 3, in every lane.
+__device__ __forceinline__ unsigned long long quad0_min_u64(unsigned long long v) {
+    v = dpp_min_u64<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_min_u64<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, 0);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), 0);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned dpp_min_u32(unsigned v) {
     const unsigned o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
     return o < v ? o : v;
 }
+// (The minimum with its operand read through the data-parallel-primitive path, one instruction
+// a step in place of copy, wait, move and minimum, measured no faster here.)
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {   // same moves as wave_min_u64
     v = dpp_min_u32<0xB1, 0xf>(v);
     v = dpp_min_u32<0x4E, 0xf>(v);
@@ -1215,10 +1227,12 @@ constexpr int kRescored = 8;  // candidates per query whose distance is recomput
 constexpr int kStretchCap = 1 << 16;    // entries of RescoreArgs::stretch_items
 
 // One wave per (problem, query): lane c holds candidate c of the query (four per train
-// split).  The kRescored candidates with the smallest ranking keys are re-scored; the rest
-// cannot be among the two nearest unless more than kRescored - 2 candidates lie within the
-// rounding of the MFMA form of the second-best distance.  (Re-scoring all of them gathered
-// 64 train rows per query: 655 MB for 20 000 queries, most of this kernel's time.)
+// split).  Up to kRescored candidates with the smallest ranking keys are re-scored, in two
+// rounds of four -- the second only when the fifth key is not out of reach of the second place
+// after the first (two queries of 20 000 on the bench sets) --; the rest cannot be among the
+// two nearest unless more than kRescored - 2 candidates lie within the rounding of the MFMA
+// form of the second-best distance.  (Re-scoring all of them gathered 64 train rows per query:
+// 655 MB for 20 000 queries, most of this kernel's time.)
 //
 // The squared differences of a re-scored row are formed by the whole wave -- lane l takes
 // elements KPL l .. KPL l + KPL - 1 of the row (one coalesced load), the loads of all the rows
@@ -1228,7 +1242,7 @@ template <int KPL>
 __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
     constexpr int K = 64 * KPL;
     constexpr int kPitch = K + 4;   // the owners' 16-byte reads fall in different banks
-    __shared__ __attribute__((aligned(16))) float s_terms[kBlock / 64][kRescored * kPitch];
+    __shared__ __attribute__((aligned(16))) float s_terms[kBlock / 64][kRescored / 2 * kPitch];
     typedef float rowslice __attribute__((ext_vector_type(KPL)));
     const int lane = threadIdx.x & 63;
     const int problem = blockIdx.y;
@@ -1261,28 +1275,27 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
         }
     }
     const int held = ti;   // (the list entry this lane holds, re-scored or not)
-    bool chosen = ncand <= kRescored;
-    unsigned ninth = 0xFFFFFFFFu;  // smallest key among the candidates not re-scored
-    if (!chosen) {
-        unsigned rest = pre;
-#pragma unroll 1
-        for (int r = 0; r < kRescored; ++r) {
-            const unsigned m = wave_min_u32(rest);
-            if (m == 0xFFFFFFFFu) break;  // wave-uniform
-            if (rest == m) {
-                chosen = true;
-                rest = 0xFFFFFFFFu;
-            }
+    // The kRescored candidates with the smallest keys, in order (a key names its lane); fifth
+    // and ninth: the smallest key behind the first round's rows and behind both rounds' rows.
+    constexpr int kRound = kRescored / 2;
+    int row_of[kRound];
+    unsigned rest = pre;
+    auto rank_round = [&]() {   // the next kRound smallest keys' rows; returns the key behind them
+#pragma unroll
+        for (int r = 0; r < kRound; ++r) {
+            const unsigned m = wave_min_u32(rest);   // (0xFFFFFFFF: none left)
+            row_of[r] = __builtin_amdgcn_readlane(ti, (int)(m & 63u));
+            if (m == 0xFFFFFFFFu) row_of[r] = -1;
+            if (rest == m) rest = 0xFFFFFFFFu;
         }
-        ninth = wave_min_u32(rest);
-    }
-    if (!chosen) ti = -1;
-    // T: no train row outside the re-scored set has a smaller ranking key (orderable form).
+        return wave_min_u32(rest);
+    };
+    const unsigned fifth = rank_round();
     // Lane 2 split + half looks at the list of that split and lane half: the key cand_third
     // bounds, and -- narrow passes -- whether both entries came from one stretch of the list's
     // rows (same_stretch: the stretch's first row; second_key: the key the stretch's other
     // rows cannot be below).
-    unsigned others = ninth;
+    unsigned lists = 0xFFFFFFFFu;
     int same_stretch = -1;
     unsigned second_key = 0xFFFFFFFFu;
     const int nt_rows = a.counts ? a.counts[tf] : a.nt_uniform;
@@ -1292,8 +1305,7 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
         const size_t o = (((size_t)problem * a.splits + split) * a.rows_cap) + q;
         const float k3 = a.cand_third[o * 2 + half];
         const unsigned u = __float_as_uint(k3);
-        const unsigned ord = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-        others = ord < others ? ord : others;
+        lists = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
     }
     if (a.stretch_rows > 0) {   // the list's entries sit in lanes 2 l and 2 l + 1
         const int i0 = __shfl(held, (2 * lane) & 63), i1 = __shfl(held, (2 * lane + 1) & 63);
@@ -1305,55 +1317,7 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
             second_key = key1;
         }
     }
-    others = wave_min_u32(others);
-    // the rows to re-score, dealt to lanes 0 .. kRescored - 1 in lane order of their holders
-    unsigned long long holders = __builtin_amdgcn_ballot_w64(ti >= 0);
-    int row_of[kRescored];
-#pragma unroll
-    for (int c = 0; c < kRescored; ++c) {
-        row_of[c] = -1;
-        if (holders) {   // wave-uniform
-            row_of[c] = __builtin_amdgcn_readlane(ti, __builtin_ctzll(holders));
-            holders &= holders - 1;
-        }
-    }
-    float* terms = s_terms[threadIdx.x >> 6];
-    {
-        const rowslice qv = *reinterpret_cast<const rowslice*>(qrow + KPL * lane);
-        rowslice tv[kRescored];
-#pragma unroll
-        for (int c = 0; c < kRescored; ++c)   // an absent row reads row 0 and is ignored
-            tv[c] = *reinterpret_cast<const rowslice*>(trows + (size_t)(row_of[c] < 0 ? 0 : row_of[c]) * K +
-                                                       KPL * lane);
-#pragma unroll
-        for (int c = 0; c < kRescored; ++c) {
-            const rowslice v = qv - tv[c];
-            *reinterpret_cast<rowslice*>(terms + c * kPitch + KPL * lane) = v * v;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();   // LDS serves a wave in order: the sums below see the terms
-    int mine = -1;
-#pragma unroll
-    for (int c = 0; c < kRescored; ++c) mine = lane == c ? row_of[c] : mine;
-    unsigned long long key = ~0ull;   // (distance, train index)
-    if (mine >= 0) {
-        // d += (a-b)*(a-b) in element order, the scalar order of OpenCV's normL2Sqr (rows are
-        // zero-padded to K floats and (0 - 0)^2 adds an exact zero)
-        const floatx4* t4 = reinterpret_cast<const floatx4*>(terms + lane * kPitch);
-        float d = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < K / 4; ++j) {
-            const floatx4 v = t4[j];
-            d += v.x;
-            d += v.y;
-            d += v.z;
-            d += v.w;
-        }
-        if (!a.squared) d = sqrtf(d);  // batchDistL2_32f
-        key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)mine;
-    }
-    const unsigned long long k0 = wave_min_u64(key);
-    const unsigned long long k1 = wave_min_u64(key == k0 ? ~0ull : key);
+    lists = wave_min_u32(lists);
     // Proof that no other row can reach the second place: its sequential squared distance is
     // at least its ranking key + ||q||^2 - E >= T + ||q||^2 - E.  E bounds the rounding of the
     // norms (pairwise sums), of the K accumulation steps of the matrix pipe (each at most one
@@ -1361,32 +1325,87 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
     // sequential sum itself (relative (K + 3) eps of a value <= 2 (||q||^2 + ||t||^2)); the
     // factor (4 K + 64) eps is more than twice their total.  The bfloat16 candidate pass has
     // three times the accumulation steps and leaves out 4 * 2^-16 of the norms (see there).
+    const double qn = (double)a.q_norms[(size_t)qf * a.rows_cap + q];
+    const double tmax = (double)a.t_norm_max[tf];
+    double E = a.key_error * (qn + tmax);
+    if (a.q_res) {
+        // fp16 pass: |q.t - q'.t'| <= |q - q'| |t| + |q| |t - t'| + |q - q'| |t - t'| for
+        // the rounded rows q', t' (Cauchy-Schwarz), twice that in the key
+        const double rq = (double)a.q_res[(size_t)qf * a.rows_cap + q], rt = (double)a.t_res_max[tf];
+        // (single-precision roots, raised past their rounding: E only has to be large enough)
+        const double root_t = (double)sqrtf((float)tmax) * 1.000001, root_q = (double)sqrtf((float)qn) * 1.000001;
+        E += 2.002 * (rq * root_t + root_q * rt + rq * rt);
+    }
+    // no row whose ranking key is at least the key of orderable form ord reaches the second
+    // place, held by second.  NORM_L2 ranks by the rounded square root, which maps neighbouring
+    // sums to one value: a row ties or wins only if its sum is below the square of the next float
+    auto out_of_reach = [&](unsigned ord, unsigned long long second) {
+        const unsigned u = ord ^ ((ord >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+        const double T = (double)__uint_as_float(u);
+        const float d1 = __uint_as_float((unsigned)(second >> 32));
+        const double d1n = (double)nextafterf(d1, INFINITY);
+        return T + qn - E > (a.squared ? (double)d1 : d1n * d1n);
+    };
+    // One round: the kRound rows of row_of re-scored, the (distance, train index) key of row c in lane c.
+    float* terms = s_terms[threadIdx.x >> 6];
+    const rowslice qv = *reinterpret_cast<const rowslice*>(qrow + KPL * lane);
+    auto score = [&]() {
+        rowslice tv[kRound];
+#pragma unroll
+        for (int c = 0; c < kRound; ++c)   // an absent row reads row 0 and is ignored
+            tv[c] = *reinterpret_cast<const rowslice*>(
+                trows + (size_t)(row_of[c] < 0 ? 0 : row_of[c]) * K + KPL * lane);
+        __builtin_amdgcn_wave_barrier();   // (the sums of the round before have read their terms)
+#pragma unroll
+        for (int c = 0; c < kRound; ++c) {
+            const rowslice v = qv - tv[c];
+            *reinterpret_cast<rowslice*>(terms + c * kPitch + KPL * lane) = v * v;
+        }
+        __builtin_amdgcn_wave_barrier();   // LDS serves a wave in order: the sums below see the terms
+        int mine = -1;
+#pragma unroll
+        for (int c = 0; c < kRound; ++c) mine = lane == c ? row_of[c] : mine;
+        unsigned long long key = ~0ull;   // (distance, train index)
+        if (mine >= 0) {
+            // d += (a-b)*(a-b) in element order, the scalar order of OpenCV's normL2Sqr (rows are
+            // zero-padded to K floats and (0 - 0)^2 adds an exact zero)
+            const floatx4* t4 = reinterpret_cast<const floatx4*>(terms + lane * kPitch);
+            float d = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < K / 4; ++j) {
+                const floatx4 v = t4[j];
+                d += v.x;
+                d += v.y;
+                d += v.z;
+                d += v.w;
+            }
+            if (!a.squared) d = sqrtf(d);  // batchDistL2_32f
+            key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)mine;
+        }
+        return key;
+    };
+    // The first round takes the four smallest keys; the second only runs when the fifth could
+    // still reach the second place (its rows cost as much to fetch as everything else here).
+    static_assert(kRound == 4, "the keys of a round sit in the first quad");
+    unsigned long long key = score();
+    unsigned long long k0 = quad0_min_u64(key);
+    unsigned long long k1 = quad0_min_u64(key == k0 ? ~0ull : key);
+    // T: no train row outside the re-scored set has a smaller ranking key (orderable form)
+    unsigned others = lists < fifth ? lists : fifth;
+    if (fifth != 0xFFFFFFFFu && (k1 == ~0ull || !out_of_reach(others, k1))) {   // wave-uniform
+        const unsigned ninth = rank_round();
+        key = score();
+        key = lane == kRound ? k0 : lane == kRound + 1 ? k1 : key;   // (lanes past the round's rows)
+        k0 = wave_min_u64(key);
+        k1 = wave_min_u64(key == k0 ? ~0ull : key);
+        others = lists < ninth ? lists : ninth;
+    }
     bool proven = true;
     const bool listed = others != 0xFFFFFFFFu || __builtin_amdgcn_ballot_w64(same_stretch >= 0) != 0;
     if (listed) {   // there are train rows outside the re-scored set
         if (k1 == ~0ull) {
             proven = false;
         } else {
-            const double qn = (double)a.q_norms[(size_t)qf * a.rows_cap + q];
-            const double tmax = (double)a.t_norm_max[tf];
-            double E = a.key_error * (qn + tmax);
-            if (a.q_res) {
-                // fp16 pass: |q.t - q'.t'| <= |q - q'| |t| + |q| |t - t'| + |q - q'| |t - t'| for
-                // the rounded rows q', t' (Cauchy-Schwarz), twice that in the key
-                const double rq = (double)a.q_res[(size_t)qf * a.rows_cap + q], rt = (double)a.t_res_max[tf];
-                E += 2.002 * (rq * sqrt(tmax) + sqrt(qn) * rt + rq * rt);
-            }
-            // no row whose ranking key is at least the key of orderable form ord reaches the
-            // second place.  NORM_L2 ranks by the rounded square root, which maps neighbouring
-            // sums to one value: a row ties or wins only if its sum is below the square of the
-            // next float
-            auto out_of_reach = [&](unsigned ord) {
-                const unsigned u = ord ^ ((ord >> 31) ? 0x80000000u : 0xFFFFFFFFu);
-                const double T = (double)__uint_as_float(u);
-                const float d1 = __uint_as_float((unsigned)(k1 >> 32));
-                const double d1n = (double)nextafterf(d1, INFINITY);
-                return T + qn - E > (a.squared ? (double)d1 : d1n * d1n);
-            };
             // A stretch that gave a list both its entries: its other rows rank behind the second
             // of them, which settles them unless that one is (nearly) the second nearest of
             // all.  Then the stretch is left to l2_exhaustive_kernel, which scores its rows one
@@ -1394,8 +1413,8 @@ __global__ __launch_bounds__(kBlock) void l2_rescore_kernel(RescoreArgs a) {
             // reach of the second place as it stands, and the second-best distance only falls.
             // Two such stretches (rare) send the query to the exhaustive pass proper.
             const unsigned long long pending =
-                __builtin_amdgcn_ballot_w64(same_stretch >= 0 && !out_of_reach(second_key));
-            proven = others == 0xFFFFFFFFu || out_of_reach(others);
+                __builtin_amdgcn_ballot_w64(same_stretch >= 0 && !out_of_reach(second_key, k1));
+            proven = others == 0xFFFFFFFFu || out_of_reach(others, k1);
             if (proven && pending) {
                 const int holder = __builtin_ctzll(pending);
                 const int first = __builtin_amdgcn_readlane(same_stretch, holder);
