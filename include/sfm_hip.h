@@ -116,7 +116,8 @@ int sfm_knn2_dev(sfm_ctx* ctx, int norm, const void* d_q, int nq, size_t q_strid
 /* Measurement aid (no counterpart in the reference): how many queries of the last L2 / L2SQR
  * call on this context (sfm_knn2*, sfm_ratio_matches, sfm_robust_matches, sfm_match_pairs_dev)
  * could not be proven exact from the matrix-core candidates and were recomputed against every
- * train row.  Synchronises the stream. */
+ * train row.  (With SFM_L2_COUNT_STRETCHES=1 in the environment it also counts the queries for
+ * which one stretch of 256 train rows was recomputed row by row.)  Synchronises the stream. */
 int sfm_l2_exhaustive_count(sfm_ctx* ctx, int* count);
 
 /* DescriptorMatcher::ratioMaches, Source Files/feature_processing.cpp:118-130:
